@@ -1,0 +1,230 @@
+// MFMA GEMM with fused bias / tanh / accumulate epilogue (gfx950).
+//
+//   C[M,N] = alpha * opA(A) * opB(B) + beta * C + bias[N]   ;  optional tanh
+//
+// Replaces every nn.Linear on the hot path (reference src/asr.py:307,316 proj+tanh; :46,69 ctc_layer;
+// :384,419 psi; :41,92 char_trans) and the x*W_ih^T halves of nn.LSTM (:473-481) and their backward
+// (dX = dY*W, dW += dY^T*X).  fp32 in HBM; operands are converted while being staged into LDS:
+// LAS_PREC_BF16 -> bf16 tiles, v_mfma_f32_16x16x32_bf16;  LAS_PREC_F32 -> f32 tiles, v_mfma_f32_16x16x4_f32.
+//
+// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles of 16x16.
+// LDS tiles are always [row][k] (k contiguous, row stride padded by 16 B so the 16-lane groups of a
+// ds_read_b128 hit distinct banks); k-strided ("transposed") sources are read coalesced along rows and
+// scattered into that layout.  Register prefetch of the next k-tile overlaps the MFMAs of the current one.
+#include "las_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+
+template <int PREC> struct Elem;
+template <> struct Elem<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int PAD = 8; };   // 16 B
+template <> struct Elem<LAS_PREC_F32>  { typedef float  T; static constexpr int PAD = 4; };   // 16 B
+
+template <typename T> __device__ __forceinline__ T cvt(float f);
+template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ float cvt<float>(float f) { return f; }
+
+// 4 consecutive source elements starting at p (stride 1), of which `cnt` (0..4) are in range.
+__device__ __forceinline__ float4 load4(const float* __restrict__ p, int cnt, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cnt >= 4 && vec) {
+        v = *(const float4*)p;
+    } else {
+        if (cnt > 0) v.x = p[0];
+        if (cnt > 1) v.y = p[1];
+        if (cnt > 2) v.z = p[2];
+        if (cnt > 3) v.w = p[3];
+    }
+    return v;
+}
+
+// Stage-in registers for one operand tile (128 rows x 32 k): 4 float4 per thread.
+// KCONT: element (r,k) at src[r*ld + k]; thread -> row = tid/8 + 32*p, k4 = (tid%8)*4.
+// else : element (r,k) at src[k*ld + r]; thread -> k = tid/32 + 8*p, r4 = (tid%32)*4.
+template <bool KCONT>
+__device__ __forceinline__ void g_load(float4 (&reg)[4], const float* __restrict__ src, long ld, int row0, int k0,
+                                       int rows, int K, bool vec) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (KCONT) {
+            const int r = row0 + (tid >> 3) + 32 * p, k = k0 + (tid & 7) * 4;
+            int cnt = (r < rows) ? min(4, K - k) : 0;
+            reg[p] = load4(src + (long)r * ld + k, cnt, vec);
+        } else {
+            const int k = k0 + (tid >> 5) + 8 * p, r = row0 + (tid & 31) * 4;
+            int cnt = (k < K) ? min(4, rows - r) : 0;
+            reg[p] = load4(src + (long)k * ld + r, cnt, vec);
+        }
+    }
+}
+
+template <bool KCONT, typename T, int LDS_LD>
+__device__ __forceinline__ void s_store(const float4 (&reg)[4], T* __restrict__ tile) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (KCONT) {
+            const int r = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
+            T* d = tile + r * LDS_LD + k;
+            d[0] = cvt<T>(reg[p].x); d[1] = cvt<T>(reg[p].y); d[2] = cvt<T>(reg[p].z); d[3] = cvt<T>(reg[p].w);
+        } else {
+            const int k = (tid >> 5) + 8 * p, r = (tid & 31) * 4;
+            tile[(r + 0) * LDS_LD + k] = cvt<T>(reg[p].x);
+            tile[(r + 1) * LDS_LD + k] = cvt<T>(reg[p].y);
+            tile[(r + 2) * LDS_LD + k] = cvt<T>(reg[p].z);
+            tile[(r + 3) * LDS_LD + k] = cvt<T>(reg[p].w);
+        }
+    }
+}
+
+template <int PREC, bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
+                                                  long lda, long sA, const float* __restrict__ B, long ldb, long sB,
+                                                  float beta, float* __restrict__ C, long ldc, long sC,
+                                                  const float* __restrict__ bias, int act, int vecA, int vecB) {
+    typedef typename Elem<PREC>::T T;
+    constexpr int LD = BK + Elem<PREC>::PAD;
+    __shared__ __attribute__((aligned(16))) T As[BM * LD];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+
+    const int bz = blockIdx.z;
+    A += (long)bz * sA; B += (long)bz * sB; C += (long)bz * sC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[4], rb[4];
+    g_load<A_KCONT>(ra, A, lda, m0, 0, M, K, vecA);
+    g_load<B_KCONT>(rb, B, ldb, n0, 0, N, K, vecB);
+    const int nk = (K + BK - 1) / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                       // previous tile's fragment reads are done
+        s_store<A_KCONT, T, LD>(ra, As);
+        s_store<B_KCONT, T, LD>(rb, Bs);
+        __syncthreads();
+        if (kt + 1 < nk) {                     // prefetch next k-tile into registers
+            g_load<A_KCONT>(ra, A, lda, m0, (kt + 1) * BK, M, K, vecA);
+            g_load<B_KCONT>(rb, B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+        }
+        if constexpr (PREC == LAS_PREC_BF16) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + (wm + i * 16 + fr) * LD + fq * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(Bs + (wn + j * 16 + fr) * LD + fq * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < BK; kb += 16) {
+                float4 af[4], bfr[4];          // lane holds k = kb + 4*fq + {0..3}; MFMA step j uses element j
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const float4*)(As + (wm + i * 16 + fr) * LD + kb + fq * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bfr[j] = *(const float4*)(Bs + (wn + j * 16 + fr) * LD + kb + fq * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + j * 16 + fr;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + fq * 4 + r;
+                if (m >= M) continue;
+                float* c = C + (long)m * ldc + n;
+                float v = alpha * acc[i][j][r] + bv;
+                if (beta != 0.f) v += beta * (*c);
+                if (act == LAS_ACT_TANH) v = tanhf(v);
+                *c = v;
+            }
+        }
+    }
+}
+
+template <int PREC>
+int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda,
+           long sA, const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
+           int act, int vecA, int vecB) {
+#define LAS_GEMM_GO(AK, BK_)                                                                                     \
+    hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
+                       sB, beta, C, ldc, sC, bias, act, vecA, vecB)
+    if (!ta && tb) LAS_GEMM_GO(true, true);
+    else if (!ta && !tb) LAS_GEMM_GO(true, false);
+    else if (ta && !tb) LAS_GEMM_GO(false, false);
+    else LAS_GEMM_GO(false, true);
+#undef LAS_GEMM_GO
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+// out[n] = beta*out[n] + sum_m X[m,n]   (bias gradients).  One block per 64 columns, 4 row groups.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float beta,
+                                                     float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < N)
+        for (int m = g; m < M; m += 4) s += X[(long)m * ld + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + t;
+    }
+}
+
+}  // namespace
+
+extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                        int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta,
+                        float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch,
+                        void* stream) {
+    LAS_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && batch >= 1);
+    LAS_CHECK_ARG(prec == LAS_PREC_BF16 || prec == LAS_PREC_F32);
+    LAS_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    if (M == 0 || N == 0) return LAS_OK;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    if (grid.y > 65535 || grid.z > 65535) return LAS_E_UNSUPPORTED;
+    const int vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (((uintptr_t)A & 15) == 0);
+    const int vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == LAS_PREC_BF16)
+        return launch<LAS_PREC_BF16>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta,
+                                     C, ldc, strideC, bias, act, vecA, vecB);
+    return launch<LAS_PREC_F32>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C,
+                                ldc, strideC, bias, act, vecA, vecB);
+}
+
+extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {
+    LAS_CHECK_ARG(X && out && M >= 0 && N > 0 && ld >= N);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, beta, out);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}

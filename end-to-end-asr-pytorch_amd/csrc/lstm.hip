@@ -1,0 +1,557 @@
+// Persistent (Bi)LSTM recurrence for gfx950: forward and back-propagation-through-time.
+//
+// Replaces the sequential half of nn.LSTM(bidirectional, packed) at reference src/asr.py:473-481 and
+// its autograd backward, including pack_padded_sequence/pad_packed_sequence (:480,483: zero output at
+// t >= len, state only advances inside the utterance) and the drop/concat time down-sampling
+// (:487-497) which is folded into the output addressing.
+//
+// Design (time-major activations):
+//   * x*W_ih^T for all timesteps and both directions is ONE MFMA GEMM done beforehand (las_gemm);
+//     this kernel receives xproj[T][B][ND*4H] and runs only the recurrence.
+//   * grid = ND * G workgroups, one per CU, all co-resident.  Workgroup (d,g) owns U (<=16) hidden units
+//     of direction d: the 4*U rows of W_hh it needs stay in LDS for all T steps (weight-stationary),
+//     the cell state c stays in registers.
+//   * per step: h_{t-1}[B,H] (published by the G workgroups of direction d) is pulled into LDS, wave w
+//     computes gate w's pre-activations with MFMA (A = h tile [16 batch x K], B = W rows [K x 16 units]),
+//     accumulators cross LDS once, the 256 threads do the pointwise cell update for (batch, unit-pair)
+//     and publish their slice of h_t.
+//   * hand-off between CUs (MI355X_MICROARCH "Valid forms", row 1): every published byte is written by an
+//     sc1 (write-through) store, every storing wave drains vmcnt(0), workgroup barrier, ONE lane adds to
+//     an agent-scope counter; consumers poll that counter with an sc1 load from one lane, workgroup
+//     barrier, then read the bytes with sc1 buffer loads (L1 bypass) only.  One workgroup per CU is
+//     enforced by the LDS request.  Spins are bounded; a timeout sets *status and every workgroup exits.
+//   * the published history doubles as the saved activations for BPTT.
+// Backward mirrors this with dgates[B,4H] as the exchanged quantity and W_hh^T columns resident.
+#include "las_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr size_t MIN_LDS = 84 * 1024;            // > 80 KiB: at most one workgroup per CU
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int PREC> struct CT;
+template <> struct CT<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int VEC = 8; static constexpr int KSTEP = 32; };
+template <> struct CT<LAS_PREC_F32>  { typedef float  T; static constexpr int VEC = 4; static constexpr int KSTEP = 16; };
+
+struct SyncWords {          // zeroed by hipMemsetAsync before every launch
+    unsigned cnt[2];        // arrivals per direction
+    unsigned abort_;        // set on spin timeout
+    unsigned pad;
+};
+
+// One lane polls `cnt >= target` (sc1 loads); returns false on timeout / abort.
+__device__ __forceinline__ bool wait_counter(unsigned* cnt, unsigned target, unsigned* abort_word) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (spins > SPIN_LIMIT) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// Block-wide wait: lane 0 polls, result broadcast through LDS word `flag`.
+__device__ __forceinline__ bool block_wait(unsigned* cnt, unsigned target, unsigned* abort_word, int* flag) {
+    if (threadIdx.x == 0) *flag = wait_counter(cnt, target, abort_word) ? 1 : 0;
+    __syncthreads();
+    return *flag != 0;
+}
+
+// Publish: every storing wave has drained its stores; one lane signals.
+__device__ __forceinline__ void block_signal(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
+    const unsigned v = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+    __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Pull a [rows x cols] row-major tile of T (published by other CUs) into LDS rows of stride `ld`,
+// 16 bytes per lane per load, sc1 (L1 bypass).  cols % VEC == 0; src 16-B aligned.
+template <typename T, int VEC>
+__device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int rows, int cols, T* __restrict__ lds,
+                                              int ld) {
+    const int vpr = cols / VEC;                                  // vectors per row
+    const int total = rows * vpr;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows * cols * (int)sizeof(T), 0x00020000);
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int r = i / vpr, c = (i - r * vpr) * VEC;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * cols + c) * (int)sizeof(T), 0, 16);
+        *(u32x4*)(lds + r * ld + c) = v;
+    }
+}
+
+// acc[bt] += A(tile rows bt*16.., k) * B(rows of Wrow.., k) over k-steps [ks0, ks1)
+template <int PREC, int NB>
+__device__ __forceinline__ void mma_rows(f32x4 (&acc)[NB], const typename CT<PREC>::T* __restrict__ Al,
+                                         const typename CT<PREC>::T* __restrict__ Bl, int ld, int ks0, int ks1) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    if constexpr (PREC == LAS_PREC_BF16) {
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const bf16x8 b = *(const bf16x8*)(Bl + fr * ld + ks * 32 + fq * 8);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                const bf16x8 a = *(const bf16x8*)(Al + (bt * 16 + fr) * ld + ks * 32 + fq * 8);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[bt], 0, 0, 0);
+            }
+        }
+    } else {
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const float4 b = *(const float4*)(Bl + fr * ld + ks * 16 + fq * 4);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                const float4 a = *(const float4*)(Al + (bt * 16 + fr) * ld + ks * 16 + fq * 4);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[bt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+struct LstmArgs {
+    int T, B, H, ND, U, G;
+    int sr, concat, T_out, F_out;
+    int y_is_hf;
+};
+
+__device__ __forceinline__ long y_offset(const LstmArgs& a, int t, int b, int d, int j, bool& ok) {
+    // layer output / its gradient, time-major [T_out][B][F_out]; concat: reference asr.py:493-494, drop: :491
+    if (a.sr == 1) { ok = true; return ((long)t * a.B + b) * a.F_out + d * a.H + j; }
+    const int u = t / a.sr, r = t - u * a.sr;
+    if (a.concat) { ok = u < a.T_out; return ((long)u * a.B + b) * a.F_out + r * (a.ND * a.H) + d * a.H + j; }
+    ok = (r == 0);
+    return ((long)u * a.B + b) * a.F_out + d * a.H + j;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int PREC, int NB>
+__global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
+                                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                      const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
+                                                      float* __restrict__ y, float* __restrict__ hf,
+                                                      typename CT<PREC>::T* __restrict__ hx, float* __restrict__ gates,
+                                                      float* __restrict__ cs, SyncWords* sync, int* status) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, B = a.B, U = a.U, ND = a.ND;
+    const int Kp = (H + KSTEP - 1) / KSTEP * KSTEP, ld = Kp + VEC;
+    const int d = blockIdx.x / a.G, g = blockIdx.x % a.G, j0 = g * U;
+    T* Wl = (T*)smem;                                   // [4][16][ld]
+    T* Hl = Wl + 4 * 16 * ld;                           // [NB*16][ld]
+    float* Gl = (float*)(Hl + NB * 16 * ld);            // [4][NB*16][17]
+    int* lensl = (int*)(Gl + 4 * NB * 16 * 17);         // [NB*16]
+    int* flag = lensl + NB * 16;
+
+    // ---- one-time staging: W_hh rows of my units (zero padded), zero h tile, lens
+    for (int i = threadIdx.x; i < 4 * 16 * ld; i += NT) {
+        const int k = i % ld, n = (i / ld) % 16, gi = i / (ld * 16);
+        float v = 0.f;
+        if (k < H && n < U && j0 + n < H) v = w_hh[((long)d * 4 * H + gi * H + j0 + n) * H + k];
+        Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
+    }
+    for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) Hl[i] = (T)0;
+    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < B ? lens[i] : 0;
+    __syncthreads();
+
+    // ---- my pointwise elements: pairs (b, n..n+1)
+    constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
+    const int half = U / 2;
+    float c_state[PP][2];
+    float bias[PP][4][2];
+    int eb[PP], en[PP];
+    bool ev[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const int e = threadIdx.x + p * NT;
+        eb[p] = e / half; en[p] = (e % half) * 2;
+        ev[p] = (e < NB * 16 * half) && eb[p] < B && (j0 + en[p] < H);
+        c_state[p][0] = c_state[p][1] = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + en[p] + q;
+                bias[p][gi][q] = (ev[p] && j < H) ? b_ih[d * 4 * H + gi * H + j] + b_hh[d * 4 * H + gi * H + j] : 0.f;
+            }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int ND4H = ND * 4 * H;
+    unsigned* cnt = &sync->cnt[d];
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = d == 0 ? s : a.T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        // (a) prefetch x-projection of my elements (independent of the recurrence)
+        float2 xp[PP][4];
+#pragma unroll
+        for (int p = 0; p < PP; ++p)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+                xp[p][gi] = ev[p] ? *(const float2*)(xproj + ((long)t * B + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p])
+                                  : make_float2(0.f, 0.f);
+        // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
+        if (s > 0) {
+            if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            pull_tile_sc1<T, VEC>(hx + ((long)d * a.T + tp) * B * H, B, H, Hl, ld);
+        }
+        __syncthreads();
+        // (d) gate pre-activations: wave w <-> gate w
+        f32x4 acc[NB];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) mma_rows<PREC, NB>(acc, Hl, Wl + wave * 16 * ld, ld, 0, Kp / KSTEP);
+        // (e) accumulators -> LDS  (C/D layout: col = lane&15 = unit, row = (lane>>4)*4 + r = batch)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
+        __syncthreads();
+        // (f) pointwise cell update, publish h_t
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (!ev[p]) continue;
+            const int b = eb[p], n = en[p], j = j0 + n;
+            const bool m = t < lensl[b];
+            float hv[2], gv[4][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float pi = Gl[(0 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][0].y : xp[p][0].x) + bias[p][0][q];
+                const float pf = Gl[(1 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][1].y : xp[p][1].x) + bias[p][1][q];
+                const float pg = Gl[(2 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][2].y : xp[p][2].x) + bias[p][2][q];
+                const float po = Gl[(3 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][3].y : xp[p][3].x) + bias[p][3][q];
+                const float ig = sigmoidf_(pi), fg = sigmoidf_(pf), gg = tanhf(pg), og = sigmoidf_(po);
+                const float cn = fg * c_state[p][q] + ig * gg;
+                const float hn = og * tanhf(cn);
+                const bool mq = m && (j + q < H);
+                c_state[p][q] = mq ? cn : c_state[p][q];
+                hv[q] = mq ? hn : 0.f;
+                gv[0][q] = mq ? ig : 0.f; gv[1][q] = mq ? fg : 0.f; gv[2][q] = mq ? gg : 0.f; gv[3][q] = mq ? og : 0.f;
+            }
+            st_pair_sc1(hx + (((long)d * a.T + t) * B + b) * H + j, hv[0], hv[1]);
+            const long ro = (long)t * B + b;
+            *(float2*)(hf + ro * (ND * H) + d * H + j) = make_float2(hv[0], hv[1]);
+            if (!a.y_is_hf) {
+                bool ok;
+                const long yo = y_offset(a, t, b, d, j, ok);
+                if (ok) *(float2*)(y + yo) = make_float2(hv[0], hv[1]);
+            }
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+                *(float2*)(gates + ro * ND4H + d * 4 * H + gi * H + j) = make_float2(gv[gi][0], gv[gi][1]);
+            *(float2*)(cs + ro * (ND * H) + d * H + j) = make_float2(m ? c_state[p][0] : 0.f, m ? c_state[p][1] : 0.f);
+        }
+        // (g) publish
+        block_signal(cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dh_rec[b][j] = sum_m dgates_next[b][m] * W_hh[m][j]; K = 4H is walked in NC chunks so the pulled
+// dgates tile fits in LDS for large H; wave w takes a quarter of each chunk's k-steps.
+template <int PREC, int NB>
+__global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4p, const float* __restrict__ dy,
+                                                      const float* __restrict__ gates, const float* __restrict__ cs,
+                                                      const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
+                                                      typename CT<PREC>::T* __restrict__ dgx, float* __restrict__ dgf,
+                                                      SyncWords* sync, int* status) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, B = a.B, U = a.U, ND = a.ND, K4 = 4 * H;
+    const int KC = K4p / NC;                              // chunk width; K4p = 4H zero-padded so KC % (4*KSTEP) == 0
+    const int ldw = K4p + VEC, ldc = KC + VEC;
+    const int d = blockIdx.x / a.G, g = blockIdx.x % a.G, j0 = g * U;
+    T* Wl = (T*)smem;                                     // [16][ldw]   W_hh^T columns of my units
+    T* Dl = Wl + 16 * ldw;                                // [NB*16][ldc] dgates_next chunk
+    float* Gl = (float*)(Dl + NB * 16 * ldc);             // [4][NB*16][17] per-wave partial sums
+    int* lensl = (int*)(Gl + 4 * NB * 16 * 17);
+    int* flag = lensl + NB * 16;
+
+    for (int i = threadIdx.x; i < 16 * ldw; i += NT) {
+        const int m = i % ldw, n = i / ldw;
+        float v = 0.f;
+        if (m < K4 && n < U && j0 + n < H) v = w_hh[((long)d * K4 + m) * H + j0 + n];
+        Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
+    }
+    for (int i = threadIdx.x; i < NB * 16 * ldc; i += NT) Dl[i] = (T)0;
+    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < B ? lens[i] : 0;
+    __syncthreads();
+
+    constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
+    const int half = U / 2;
+    float dc_carry[PP][2];
+    int eb[PP], en[PP];
+    bool ev[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const int e = threadIdx.x + p * NT;
+        eb[p] = e / half; en[p] = (e % half) * 2;
+        ev[p] = (e < NB * 16 * half) && eb[p] < B && (j0 + en[p] < H);
+        dc_carry[p][0] = dc_carry[p][1] = 0.f;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int ND4H = ND * K4, NDH = ND * H;
+    unsigned* cnt = &sync->cnt[d];
+    const int kq = KC / KSTEP / 4;                        // k-steps per wave per chunk
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = d == 0 ? a.T - 1 - s : s;           // reverse of the forward processing order
+        const int tn = d == 0 ? t + 1 : t - 1;            // step handled just before (later in forward order)
+        const int tp = d == 0 ? t - 1 : t + 1;            // previous step in forward order (c_{prev})
+        // (a) prefetch saved activations and the incoming gradient
+        float2 sg[PP][4], sc[PP], scp[PP], sdy[PP];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            sc[p] = scp[p] = sdy[p] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) sg[p][gi] = make_float2(0.f, 0.f);
+            if (!ev[p]) continue;
+            const int b = eb[p], j = j0 + en[p];
+            if (t >= lensl[b]) continue;
+            const long ro = (long)t * B + b;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) sg[p][gi] = *(const float2*)(gates + ro * ND4H + d * K4 + gi * H + j);
+            sc[p] = *(const float2*)(cs + ro * NDH + d * H + j);
+            if (tp >= 0 && tp < lensl[b]) scp[p] = *(const float2*)(cs + ((long)tp * B + b) * NDH + d * H + j);
+            bool ok;
+            const long yo = y_offset(a, t, b, d, j, ok);
+            if (ok) sdy[p] = *(const float2*)(dy + yo);
+        }
+        // (b,c,d) dh_rec from the previous step's dgates
+        f32x4 acc[NB];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            const T* src = dgx + ((long)d * a.T + tn) * B * K4;
+            for (int c = 0; c < NC; ++c) {
+                if (c > 0) __syncthreads();               // previous chunk fully consumed
+                // rows have stride K4 in memory, KC columns starting at c*KC
+                {
+                    const int kreal = min(KC, K4 - c * KC);       // real (unpadded) columns of this chunk
+                    const int vpr = kreal / VEC, total = B * vpr;
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, B * K4 * (int)sizeof(T), 0x00020000);
+                    for (int i = threadIdx.x; i < total; i += NT) {
+                        const int r = i / vpr, cc = (i - r * vpr) * VEC;
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * K4 + c * KC + cc) * (int)sizeof(T), 0, 16);
+                        *(u32x4*)(Dl + r * ldc + cc) = v;
+                    }
+                }
+                __syncthreads();
+                // A = Dl rows (batch) x k ; B = Wl rows (unit) x k, offset to this chunk/wave quarter
+                {
+                    const T* Ab = Dl + wave * kq * KSTEP;
+                    const T* Bb = Wl + c * KC + wave * kq * KSTEP;
+                    if constexpr (PREC == LAS_PREC_BF16) {
+                        for (int ks = 0; ks < kq; ++ks) {
+                            const bf16x8 bv = *(const bf16x8*)(Bb + fr * ldw + ks * 32 + fq * 8);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) {
+                                const bf16x8 av = *(const bf16x8*)(Ab + (bt * 16 + fr) * ldc + ks * 32 + fq * 8);
+                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[bt], 0, 0, 0);
+                            }
+                        }
+                    } else {
+                        for (int ks = 0; ks < kq; ++ks) {
+                            const float4 bv = *(const float4*)(Bb + fr * ldw + ks * 16 + fq * 4);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) {
+                                const float4 av = *(const float4*)(Ab + (bt * 16 + fr) * ldc + ks * 16 + fq * 4);
+                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[bt], 0, 0, 0);
+                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[bt], 0, 0, 0);
+                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[bt], 0, 0, 0);
+                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[bt], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
+        __syncthreads();
+        // (f) pointwise BPTT, publish dgates_t
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (!ev[p]) continue;
+            const int b = eb[p], n = en[p], j = j0 + n;
+            const bool m = t < lensl[b];
+            float dg[4][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float dh_rec = Gl[(0 * NB * 16 + b) * 17 + n + q] + Gl[(1 * NB * 16 + b) * 17 + n + q] +
+                                     Gl[(2 * NB * 16 + b) * 17 + n + q] + Gl[(3 * NB * 16 + b) * 17 + n + q];
+                const float ig = q ? sg[p][0].y : sg[p][0].x, fg = q ? sg[p][1].y : sg[p][1].x;
+                const float gg = q ? sg[p][2].y : sg[p][2].x, og = q ? sg[p][3].y : sg[p][3].x;
+                const float ct = q ? sc[p].y : sc[p].x, cp = q ? scp[p].y : scp[p].x;
+                const float dh = (q ? sdy[p].y : sdy[p].x) + dh_rec;
+                const float tc = tanhf(ct);
+                const float dc = dh * og * (1.f - tc * tc) + dc_carry[p][q];
+                const bool mq = m && (j + q < H);
+                dg[0][q] = mq ? dc * gg * ig * (1.f - ig) : 0.f;
+                dg[1][q] = mq ? dc * cp * fg * (1.f - fg) : 0.f;
+                dg[2][q] = mq ? dc * ig * (1.f - gg * gg) : 0.f;
+                dg[3][q] = mq ? dh * tc * og * (1.f - og) : 0.f;
+                dc_carry[p][q] = mq ? dc * fg : 0.f;
+            }
+            const long ro = (long)t * B + b;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                st_pair_sc1(dgx + (((long)d * a.T + t) * B + b) * K4 + gi * H + j, dg[gi][0], dg[gi][1]);
+                *(float2*)(dgf + ro * ND4H + d * K4 + gi * H + j) = make_float2(dg[gi][0], dg[gi][1]);
+            }
+        }
+        block_signal(cnt);
+    }
+}
+
+size_t fwd_lds(int prec, int H, int NB) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ks = prec == LAS_PREC_BF16 ? 32 : 16;
+    const int Kp = (H + ks - 1) / ks * ks, ld = Kp + vec;
+    return (size_t)(4 * 16 + NB * 16) * ld * sz + sizeof(float) * 4 * NB * 16 * 17 + sizeof(int) * (NB * 16 + 4);
+}
+int bwd_k4p(int prec, int H) {
+    const int q = 4 * (prec == LAS_PREC_BF16 ? 32 : 16);
+    return (4 * H + q - 1) / q * q;
+}
+size_t bwd_lds(int prec, int H, int NB, int NC) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4;
+    const int K4p = bwd_k4p(prec, H), KC = K4p / NC;
+    return (size_t)16 * (K4p + vec) * sz + (size_t)NB * 16 * (KC + vec) * sz + sizeof(float) * 4 * NB * 16 * 17 +
+           sizeof(int) * (NB * 16 + 4);
+}
+constexpr size_t LDS_CAP = 160 * 1024;
+
+int pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
+
+int check_common(int T, int B, int H, int ND, int sr) {
+    if (T <= 0 || B <= 0 || H <= 0 || (ND != 1 && ND != 2) || sr < 1) return LAS_E_BADARG;
+    if (H % 8 != 0) return LAS_E_UNSUPPORTED;          // 16-byte exchange vectors / pair stores
+    if (pick_nb(B) == 0) return LAS_E_UNSUPPORTED;
+    return LAS_OK;
+}
+
+void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int concat) {
+    a.T = T; a.B = B; a.H = H; a.ND = ND; a.U = U; a.G = (H + U - 1) / U;
+    a.sr = sr; a.concat = concat;
+    if (sr == 1) { a.T_out = T; a.F_out = ND * H; }
+    else if (concat) { a.T_out = T / sr; a.F_out = sr * ND * H; }
+    else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
+    a.y_is_hf = 0;
+}
+
+template <int PREC, int NB>
+int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
+               const float* w_hh, const int32_t* lens, float* y, float* hf, void* hx, float* gates, float* cs,
+               SyncWords* sync, int* status) {
+    auto k = lstm_fwd_kernel<PREC, NB>;
+    LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(a.ND * a.G), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+                       (typename CT<PREC>::T*)hx, gates, cs, sync, status);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+template <int PREC, int NB>
+int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, const float* dy, const float* gates,
+               const float* cs, const float* w_hh, const int32_t* lens, void* dgx, float* dgf, SyncWords* sync,
+               int* status) {
+    auto k = lstm_bwd_kernel<PREC, NB>;
+    LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(a.ND * a.G), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
+                       (typename CT<PREC>::T*)dgx, dgf, sync, status);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+#define LAS_NB_SWITCH(NBV, CALL)            \
+    switch (NBV) {                          \
+        case 1: { constexpr int NB_ = 1; CALL; } break; \
+        case 2: { constexpr int NB_ = 2; CALL; } break; \
+        case 4: { constexpr int NB_ = 4; CALL; } break; \
+        case 8: { constexpr int NB_ = 8; CALL; } break; \
+        default: return LAS_E_UNSUPPORTED;  \
+    }
+
+}  // namespace
+
+extern "C" void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out) {
+    LstmArgs a;
+    fill_args(a, T, 1, H, ND, 16, sr, concat);
+    *T_out = a.T_out; *F_out = a.F_out;
+}
+
+extern "C" size_t las_lstm_sync_bytes(void) { return 256; }
+
+extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
+                                const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
+                                float* hf, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
+    LAS_CHECK_ARG(xproj && b_ih && b_hh && w_hh && lens && y && hf && hx && gates && cs && sync && status);
+    int rc = check_common(T, B, H, ND, sr);
+    if (rc) return rc;
+    const int NB = pick_nb(B);
+    int U = 16;
+    size_t lds = fwd_lds(prec, H, NB);
+    if (lds > LDS_CAP || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    // use more, smaller slices when the chip has room (shorter MFMA chains per step)
+    if (ND * ((H + 7) / 8) <= 256 && H >= 512) U = 8;
+    LstmArgs a;
+    fill_args(a, T, B, H, ND, U, sr, concat);
+    a.y_is_hf = (y == hf);
+    if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
+    if (lds < MIN_LDS) lds = MIN_LDS;
+    hipStream_t st = (hipStream_t)stream;
+    LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+    if (prec == LAS_PREC_BF16) {
+        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_>(a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status)));
+    } else if (prec == LAS_PREC_F32) {
+        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_F32, NB_>(a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status)));
+    }
+    return LAS_E_BADARG;
+}
+
+extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
+                                const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx,
+                                float* dgf, void* sync, int* status, void* stream) {
+    LAS_CHECK_ARG(dy && gates && cs && w_hh && lens && dgx && dgf && sync && status);
+    int rc = check_common(T, B, H, ND, sr);
+    if (rc) return rc;
+    const int NB = pick_nb(B);
+    if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
+    const int ks = prec == LAS_PREC_BF16 ? 32 : 16;
+    const int K4p = bwd_k4p(prec, H);
+    int NC = 1;                                                  // chunks must keep whole k-steps per wave and be unpadded if >1
+    while (NC <= 8 && (bwd_lds(prec, H, NB, NC) > LDS_CAP || (K4p / NC) % (4 * ks) != 0 || (NC > 1 && K4p != 4 * H))) NC *= 2;
+    if (NC > 8 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    LstmArgs a;
+    fill_args(a, T, B, H, ND, 16, sr, concat);
+    size_t lds = bwd_lds(prec, H, NB, NC);
+    if (lds < MIN_LDS) lds = MIN_LDS;
+    hipStream_t st = (hipStream_t)stream;
+    LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+    if (prec == LAS_PREC_BF16) {
+        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_>(a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status)));
+    } else if (prec == LAS_PREC_F32) {
+        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_F32, NB_>(a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status)));
+    }
+    return LAS_E_BADARG;
+}

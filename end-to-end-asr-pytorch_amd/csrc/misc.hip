@@ -1,0 +1,94 @@
+// Small data-movement / elementwise kernels around the hot ops (all HBM-bound, vectorised where aligned).
+#include "las_common.h"
+
+namespace {
+
+// out[d1][d0][:] = in[d0][d1][:]   (batch-major <-> time-major activations)
+__global__ __launch_bounds__(256) void transpose01_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int D0, int D1, int F) {
+    const long row = blockIdx.x;                 // over D0*D1 input rows
+    const int d0 = row / D1, d1 = row % D1;
+    const float* s = in + row * F;
+    float* o = out + ((long)d1 * D0 + d0) * F;
+    if ((F & 3) == 0) {
+        for (int i = threadIdx.x; i < F / 4; i += 256) ((float4*)o)[i] = ((const float4*)s)[i];
+    } else {
+        for (int i = threadIdx.x; i < F; i += 256) o[i] = s[i];
+    }
+}
+
+// out = dy * (1 - y^2)        (backward of y = tanh(.), reference asr.py:316)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ out, long n) {
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        const float4 a = *(const float4*)(dy + i), b = *(const float4*)(y + i);
+        *(float4*)(out + i) = make_float4(a.x * (1.f - b.x * b.x), a.y * (1.f - b.y * b.y), a.z * (1.f - b.z * b.z),
+                                          a.w * (1.f - b.w * b.w));
+    }
+    if (i < n && i + 3 >= n)
+        for (long k = i; k < n; ++k) out[k] = dy[k] * (1.f - y[k] * y[k]);
+}
+
+// lens[b] = #frames whose feature sum != 0   (reference solver.py:134, done on the host there)
+__global__ __launch_bounds__(256) void infer_lengths_kernel(const float* __restrict__ x, int T, int D,
+                                                            int32_t* __restrict__ lens) {
+    __shared__ float red[32];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float cnt = 0.f;
+    for (int t = w; t < T; t += 4) {
+        const float* r = x + ((long)b * T + t) * D;
+        float s = 0.f;
+        for (int i = lane; i < D; i += 64) s += r[i];
+        s = wave_sum(s);
+        if (s != 0.f) cnt += 1.f;
+    }
+    if (lane != 0) cnt = 0.f;
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) lens[b] = (int)cnt;
+}
+
+// out[b] = #nonzero labels in y[b,:] (int64)   (reference solver.py:136,159)
+__global__ __launch_bounds__(64) void count_nonzero_i64_kernel(const long long* __restrict__ y, int L,
+                                                               int32_t* __restrict__ out) {
+    const int b = blockIdx.x;
+    float c = 0.f;
+    for (int i = threadIdx.x; i < L; i += 64) c += (y[(long)b * L + i] != 0) ? 1.f : 0.f;
+    c = wave_sum(c);
+    if (threadIdx.x == 0) out[b] = (int)c;
+}
+
+}  // namespace
+
+extern "C" int las_transpose01(const float* in, float* out, int D0, int D1, int F, void* stream) {
+    LAS_CHECK_ARG(in && out && D0 > 0 && D1 > 0 && F > 0);
+    hipLaunchKernelGGL(transpose01_kernel, dim3((unsigned)((long)D0 * D1)), dim3(256), 0, (hipStream_t)stream, in, out, D0, D1, F);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+    LAS_CHECK_ARG(dy && y && out && n >= 0);
+    if (n == 0) return LAS_OK;
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, (long)n);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_infer_lengths(const float* x, int B, int T, int D, int32_t* lens, void* stream) {
+    LAS_CHECK_ARG(x && lens && B > 0 && T > 0 && D > 0);
+    hipLaunchKernelGGL(infer_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, T, D, lens);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_count_nonzero_i64(const int64_t* y, int B, int L, int32_t* out, void* stream) {
+    LAS_CHECK_ARG(y && out && B > 0 && L > 0);
+    hipLaunchKernelGGL(count_nonzero_i64_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)y, L, out);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}

@@ -55,6 +55,39 @@ int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha,
 /* out[n] = beta*out[n] + sum_m X[m,n]  (bias gradients of the layers above). */
 int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream);
 
+/* ---- Persistent (Bi)LSTM recurrence, time-major -------------------------------------------------
+ * Replaces the sequential half of nn.LSTM(bidirectional, batch_first, packed) and its BPTT at
+ * src/asr.py:473-484, incl. pack/pad semantics (:480,483) and the drop/concat down-sampling (:487-497).
+ * The input projection x*W_ih^T is a separate las_gemm.  Shapes (ND = 1|2 directions, gate order i,f,g,o):
+ *   xproj [T][B][ND*4H] (no bias), b_ih/b_hh [ND*4H], w_hh [ND][4H][H], lens [B] (desc. order not required)
+ *   y     [T_out][B][F_out] layer output in next-layer layout (see las_lstm_out_shape); zero at t>=len
+ *   hf    [T][B][ND*H] hidden history (fp32); may alias y when sr==1
+ *   hx    [ND][T][B][H] exchange copy in the MFMA operand type (bf16: 2 B/elem, f32: 4 B/elem)
+ *   gates [T][B][ND*4H] post-activation gates, cs [T][B][ND*H] cell states (saved for bwd)
+ *   sync  las_lstm_sync_bytes() bytes of scratch; status: int32, caller-zeroed, set to LAS_E_TIMEOUT if
+ *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).
+ * bwd: dy [T_out][B][F_out] -> dgf [T][B][ND*4H] (= d loss / d xproj, fp32) and dgx [ND][T][B][4H]
+ * (exchange copy, operand type).  dW_ih, dW_hh, db, dx follow from dgf through las_gemm / las_colsum.
+ * Limits: H % 8 == 0, B <= 128, ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
+void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
+size_t las_lstm_sync_bytes(void);
+int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
+                     const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
+                     void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
+int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
+                     const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx, float* dgf,
+                     void* sync, int* status, void* stream);
+
+/* ---- small data-movement / elementwise kernels ------------------------------------------------- */
+/* out[d1][d0][:] = in[d0][d1][:] (batch-major <-> time-major; replaces the implicit layout of batch_first) */
+int las_transpose01(const float* in, float* out, int D0, int D1, int F, void* stream);
+/* out = dy*(1-y^2): backward of torch.tanh at src/asr.py:316,419 */
+int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);
+/* lens[b] = #frames of x[b] whose feature sum != 0 (src/solver.py:134, on the host there) */
+int las_infer_lengths(const float* x, int B, int T, int D, int32_t* lens, void* stream);
+/* out[b] = #nonzero entries of y[b,:] (src/solver.py:136,159) */
+int las_count_nonzero_i64(const int64_t* y, int B, int L, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,7 +73,7 @@ def test_ctc_random_vs_oracle(las, B, T, V, L, seed):
     enc_len = rng.randint(min(T, 2 * L + 1), T + 1, size=B); enc_len[0] = T
     nll, la, grad = run_hip(las, logits, label, enc_len, tgt_len)
     onll, ola, ograd = ctc_ref(logits, label, enc_len, tgt_len)
-    compare(nll, la, grad, onll, ola, ograd, enc_len, tgt_len, atol_g=5e-5)  # fp32 lattice vs fp64 oracle
+    compare(nll, la, grad, onll, ola, ograd, enc_len, tgt_len, atol_g=2e-4)  # fp32 lattice (<=700 sequential log-adds) vs fp64 oracle
 
 
 def test_ctc_full_size_properties(las):

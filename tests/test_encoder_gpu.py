@@ -1,0 +1,124 @@
+"""GPU parity: persistent (Bi)LSTM layer + Listener vs golden vectors from the imported reference.
+f32 mode (exact f32 MFMA): atol 2e-5/rtol 1e-4.  bf16 mode (bf16 MFMA operands, fp32 accumulate/state):
+atol 3e-2 on O(1) activations and grads (stated tolerance of the bf16 path)."""
+import importlib
+import os
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = {'f32': dict(atol=2e-5, rtol=1e-4), 'bf16': dict(atol=3e-2, rtol=3e-2)}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    importlib.import_module('end-to-end-asr-pytorch_amd')
+    return importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+
+
+def T_(a, grad=False):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV, requires_grad=grad)
+
+
+def cat_lstm_weights(d, prefix, bidir):
+    sfx = ['', '_reverse'] if bidir else ['']
+    w_ih = np.concatenate([d[f'{prefix}weight_ih_l0{s}'] for s in sfx], 0)
+    w_hh = np.stack([d[f'{prefix}weight_hh_l0{s}'] for s in sfx], 0)
+    b_ih = np.concatenate([d[f'{prefix}bias_ih_l0{s}'] for s in sfx], 0)
+    b_hh = np.concatenate([d[f'{prefix}bias_hh_l0{s}'] for s in sfx], 0)
+    return w_ih, w_hh, b_ih, b_hh
+
+
+def close(a, b, tol):
+    np.testing.assert_allclose(a.detach().cpu().numpy() if torch.is_tensor(a) else a, b, **tol)
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+@pytest.mark.parametrize('name,style', [('concat_odd', 'concat'), ('drop_odd', 'drop'), ('sr1', 'concat'),
+                                        ('uni_concat3', 'concat')])
+def test_rnnlayer_golden(ops, name, style, prec):
+    d = np.load(os.path.join(GOLDEN, f'g1_rnnlayer_{name}.npz'))
+    bidir, sr = bool(d['bidir']), int(d['sr'])
+    w_ih, w_hh, b_ih, b_hh = [T_(v, True) for v in cat_lstm_weights(d, 'w.layer.', bidir)]
+    x = T_(d['x'], True)
+    lens = torch.tensor(d['lens'], dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.set_precision(prec)
+    try:
+        x_tm = ops.Transpose01Fn.apply(x)
+        y_tm = ops.lstm_layer(x_tm, lens, w_ih, w_hh, b_ih, b_hh, sr, style == 'concat', status)
+        y = ops.Transpose01Fn.apply(y_tm)
+        (y * T_(d['gy'])).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    assert int(status.item()) == 0
+    tol = TOL[prec]
+    close(y, d['y'], tol)
+    close(x.grad, d['gx'], tol)
+    gw_ih, gw_hh, gb_ih, gb_hh = cat_lstm_weights(d, 'grad.layer.', bidir)
+    close(w_ih.grad, gw_ih, tol)
+    close(w_hh.grad, gw_hh, tol)
+    close(b_ih.grad, gb_ih, tol)
+    close(b_hh.grad, gb_hh, tol)
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+def test_lstm_vs_oracle_medium(ops, prec):
+    """H=64, B=20 (2 batch tiles), ragged, T=37: against the oracle's explicit time loop."""
+    from oracle import las_ref as R
+    rng = np.random.RandomState(5)
+    T, B, Iin, H = 37, 20, 24, 64
+    lens = sorted(rng.randint(5, T + 1, size=B).tolist(), reverse=True); lens[0] = T
+    x = np.zeros((B, T, Iin), np.float32)
+    for b, l in enumerate(lens):
+        x[b, :l] = rng.randn(l, Iin)
+    W = {}
+    for sfx in ['', '_reverse']:
+        W['L.layer.weight_ih_l0' + sfx] = torch.tensor((rng.randn(4 * H, Iin) / np.sqrt(Iin)).astype(np.float32), requires_grad=True)
+        W['L.layer.weight_hh_l0' + sfx] = torch.tensor((rng.randn(4 * H, H) / np.sqrt(H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_ih_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_hh_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+    xr = torch.tensor(x, requires_grad=True)
+    yr, olen = R.rnn_layer(xr, lens, W, 'L', 2, 'concat', True)
+    gy = rng.randn(*yr.shape).astype(np.float32)
+    (yr * torch.tensor(gy)).sum().backward()
+    dd = {k[len('L.layer.'):]: v.detach().numpy() for k, v in W.items()}
+    gd = {k[len('L.layer.'):]: v.grad.numpy() for k, v in W.items()}
+    w_ih, w_hh, b_ih, b_hh = [T_(v, True) for v in cat_lstm_weights(dd, '', True)]
+    xg = T_(x, True)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.set_precision(prec)
+    try:
+        y = ops.Transpose01Fn.apply(ops.lstm_layer(ops.Transpose01Fn.apply(xg), torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                                   w_ih, w_hh, b_ih, b_hh, 2, True, status))
+        (y * T_(gy)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    assert int(status.item()) == 0
+    tol = dict(atol=1e-4, rtol=1e-3) if prec == 'f32' else dict(atol=8e-2, rtol=5e-2)
+    close(y, yr.detach().numpy(), tol)
+    close(xg.grad, xr.grad.numpy(), tol)
+    g_ih, g_hh, g_bi, g_bh = cat_lstm_weights(gd, '', True)
+    scale = max(1.0, np.abs(g_hh).max())
+    close(w_ih.grad / scale, g_ih / scale, tol)
+    close(w_hh.grad / scale, g_hh / scale, tol)
+    close(b_ih.grad / scale, g_bi / scale, tol)
+
+
+def test_infer_lengths_and_transpose(ops):
+    rng = np.random.RandomState(1)
+    x = np.zeros((5, 17, 6), np.float32)
+    lens = [17, 11, 9, 3, 1]
+    for b, l in enumerate(lens):
+        x[b, :l] = rng.randn(l, 6)
+    xg = T_(x)
+    assert ops.infer_lengths(xg).cpu().tolist() == lens
+    np.testing.assert_array_equal(ops.transpose01(xg).cpu().numpy(), x.transpose(1, 0, 2))
+    y = torch.tensor([[0, 3, 4, 1, 0], [0, 2, 1, 0, 0]], device=DEV)
+    assert ops.count_nonzero(y).cpu().tolist() == [3, 2]

@@ -1,0 +1,293 @@
+// Attend-and-spell decoder loop (forward), one C-ABI call for all L steps.
+//
+// Replaces the Python loop at reference src/asr.py:84-107: Attention.forward (:410-457, modes 'dot' and
+// 'loc', softmax scale 2.0, -inf mask beyond enc_len, context over the RAW encoder features), the Speller
+// stack of nn.LSTMCell (:352-357), the embedding look-ups (:74,79,100,102) and the scheduled-sampling /
+// greedy feedback (:95-102).  No per-step device->host traffic (the reference does a.cpu() per step, :107).
+//
+// Per step: q = tanh(phi h0_{t-1})            skinny MFMA product, tanh epilogue
+//           energies e[b,t']                   att_energy_fwd   grid (T'-chunks, B)   HBM-bound on psi(enc)
+//           softmax(2e), context               att_softmax_ctx  grid (E-chunks, B)    HBM-bound on enc
+//           LSTM cells                         skinny MFMA product, cell epilogue
+// Everything needed by the backward pass is kept in caller-owned buffers (las_dec_state).
+#include "las_mma.h"
+
+int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                      long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                      long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                      long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                      float* gates_out, hipStream_t st);
+
+namespace {
+
+constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;     // reference asr.py:395-398
+constexpr float ATT_SCALE = 2.0f;                                 // reference asr.py:410
+
+// rows[r][0:C] = emb[tok(r)]; tok from int64 teacher labels y[b][t] (r = t*B + b) or from int32 tok[r]
+__global__ __launch_bounds__(256) void embed_rows_kernel(const float* __restrict__ emb, const long long* __restrict__ y,
+                                                         int Ly, const int32_t* __restrict__ tok_in, int B, int C,
+                                                         int V, float* __restrict__ out, long ldo,
+                                                         int32_t* __restrict__ tok_out) {
+    const int r = blockIdx.x, t = r / B, b = r % B;
+    int tk = tok_in ? tok_in[r] : (int)y[(long)b * Ly + t];
+    tk = min(max(tk, 0), V - 1);
+    if (tok_out && threadIdx.x == 0) tok_out[r] = tk;
+    const float* s = emb + (long)tk * C;
+    float* o = out + (long)r * ldo;
+    for (int i = threadIdx.x; i < C; i += 256) o[i] = s[i];
+}
+
+// prev[b][t'] = 1/len for t' < len else 0   (reference asr.py:444-449)
+__global__ void uniform_att_kernel(const int32_t* __restrict__ lens, int Tp, float* __restrict__ prev) {
+    const int b = blockIdx.x, l = lens[b];
+    for (int i = threadIdx.x; i < Tp; i += blockDim.x) prev[(long)b * Tp + i] = i < l ? 1.f / (float)l : 0.f;
+}
+
+struct AttArgs {
+    int B, Tp, E, A, loc, TC;
+    const float* psi; const float* enc; const int32_t* lens;
+    const float* q;           // [B][A] this step
+    const float* prev;        // [B][Tp] previous attention (loc)
+    const float* conv_w; const float* w_lp; const float* w_e; const float* b_e;
+    float* e;                 // [B][Tp]
+    float* f;                 // [B][10][Tp]  (loc, saved)
+    float* s;                 // [B][Tp][A]   (loc, saved)
+};
+
+// grid (NCH, B): energies of T'-chunk [t0, t0+TC) of utterance b
+template <bool LOC>
+__global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y, t0 = blockIdx.x * a.TC, len = a.lens[b];
+    const int t1 = min(t0 + a.TC, a.Tp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* q_l = sm;                                 // [A]
+    for (int i = threadIdx.x; i < a.A; i += 256) q_l[i] = a.q[(long)b * a.A + i];
+    if (!LOC) {
+        __syncthreads();
+        for (int t = t0 + wave; t < t1; t += 4) {
+            float acc = 0.f;
+            if (t < len) {
+                const float* p = a.psi + ((long)b * a.Tp + t) * a.A;
+                for (int i = lane; i < a.A; i += 64) acc += p[i] * q_l[i];
+                acc = wave_sum(acc);
+            }
+            if (lane == 0) a.e[(long)b * a.Tp + t] = acc;
+        }
+        return;
+    }
+    float* we_l = q_l + a.A;                         // [A]
+    float* wlp_l = we_l + a.A;                       // [10][A] (transposed: conflict-free over a)
+    float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
+    float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
+    float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]
+    for (int i = threadIdx.x; i < a.A; i += 256) we_l[i] = a.w_e[i];
+    for (int i = threadIdx.x; i < LOC_C * a.A; i += 256) { const int aa = i / LOC_C, c = i % LOC_C; wlp_l[c * a.A + aa] = a.w_lp[i]; }
+    for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) cw_l[i] = a.conv_w[i];
+    for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
+        const int t = t0 - LOC_K + i;
+        prev_l[i] = (t >= 0 && t < a.Tp) ? a.prev[(long)b * a.Tp + t] : 0.f;
+    }
+    __syncthreads();
+    // location features f[c][t] = sum_k w[c][k] * prev[t + k - K]
+    for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
+        const int c = i / a.TC, tt = i % a.TC;
+        float acc = 0.f;
+        if (t0 + tt < t1) {
+            const float* w = cw_l + c * LOC_W;
+            const float* p = prev_l + tt;
+#pragma unroll 3
+            for (int k = 0; k < LOC_W; ++k) acc += w[k] * p[k];
+            a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] = acc;
+        }
+        f_l[c * a.TC + tt] = acc;
+    }
+    __syncthreads();
+    const float be = a.b_e[0];
+    for (int t = t0 + wave; t < t1; t += 4) {
+        float acc = 0.f;
+        const int tt = t - t0;
+        if (t < len) {
+            const float* p = a.psi + ((long)b * a.Tp + t) * a.A;
+            float* so = a.s + ((long)b * a.Tp + t) * a.A;
+            float fc[LOC_C];
+#pragma unroll
+            for (int c = 0; c < LOC_C; ++c) fc[c] = f_l[c * a.TC + tt];
+            for (int i = lane; i < a.A; i += 64) {
+                float u = 0.f;
+#pragma unroll
+                for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
+                u = fast_tanh(u);
+                const float sv = fast_tanh(p[i] + q_l[i] + u);
+                so[i] = sv;
+                acc += we_l[i] * sv;
+            }
+            acc = wave_sum(acc) + be;
+        }
+        if (lane == 0) a.e[(long)b * a.Tp + t] = acc;
+    }
+}
+
+// grid (ECH, B): masked softmax(2e) over T' (recomputed per block: T' floats), context for 64 columns of E
+__global__ __launch_bounds__(256) void att_softmax_ctx(int Tp, int E, const float* __restrict__ e,
+                                                       const float* __restrict__ enc, const int32_t* __restrict__ lens,
+                                                       float* __restrict__ att_out, float* __restrict__ ctx_out,
+                                                       long ld_ctx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* a_l = sm;                 // [Tp]
+    float* red = sm + Tp;            // [32]
+    float* part = red + 32;          // [4][64]
+    const int b = blockIdx.y, len = lens[b];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < len; i += 256) { const float v = ATT_SCALE * e[(long)b * Tp + i]; a_l[i] = v; m = fmaxf(m, v); }
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) { const float v = expf(a_l[i] - m); a_l[i] = v; s += v; }
+    s = block_sum(s, red);
+    const float inv = 1.f / s;
+    for (int i = threadIdx.x; i < Tp; i += 256) {
+        const float v = i < len ? a_l[i] * inv : 0.f;
+        a_l[i] = v;
+        if (blockIdx.x == 0) att_out[(long)b * Tp + i] = v;
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), tg = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (col < E) {
+        const float* p = enc + (long)b * Tp * E + col;
+        for (int t = tg; t < len; t += 4) acc += a_l[t] * p[(long)t * E];
+    }
+    part[tg * 64 + (threadIdx.x & 63)] = acc;
+    __syncthreads();
+    if (tg == 0 && col < E)
+        ctx_out[(long)b * ld_ctx + col] = part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
+}
+
+// next token: argmax (greedy, reference asr.py:102) or a draw from softmax(logits) (asr.py:99)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void pick_token_kernel(const float* __restrict__ logits, int V, int greedy,
+                                                         unsigned seed, int32_t* __restrict__ tok) {
+    __shared__ float red[32];
+    __shared__ float bestv[256];
+    __shared__ int besti[256];
+    const int b = blockIdx.x;
+    const float* x = logits + (long)b * V;
+    float bv = -INFINITY; int bi = 0;
+    if (greedy) {
+        for (int i = threadIdx.x; i < V; i += 256) if (x[i] > bv) { bv = x[i]; bi = i; }
+    } else {
+        // Gumbel-max: argmax_i (x_i + g_i), g_i = -log(-log(u_i))
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const unsigned h = hash32(seed ^ hash32((unsigned)(b * 0x9e3779b9u + i)));
+            const float u = ((h >> 8) + 0.5f) * (1.f / 16777216.f);
+            const float v = x[i] - logf(-logf(u));
+            if (v > bv) { bv = v; bi = i; }
+        }
+    }
+    bestv[threadIdx.x] = bv; besti[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float ov = bestv[threadIdx.x + o]; const int oi = besti[threadIdx.x + o];
+            if (ov > bestv[threadIdx.x] || (ov == bestv[threadIdx.x] && oi < besti[threadIdx.x])) { bestv[threadIdx.x] = ov; besti[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tok[b] = besti[0];
+    (void)red;
+}
+
+int att_chunks(int Tp) { int n = (Tp + 63) / 64; return n < 1 ? 1 : (n > 16 ? 16 : n); }
+
+}  // namespace
+
+extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                               const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode,
+                               unsigned seed, las_dec_state* st_, void* stream) {
+    LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_);
+    const int B = d->B, Tp = d->Tp, E = d->E, A = d->A, C = d->C, NL = d->NL, V = d->V, L = d->L, loc = d->loc, prec = d->prec;
+    LAS_CHECK_ARG(B > 0 && Tp > 0 && E > 0 && A > 0 && C > 0 && NL >= 1 && NL <= 4 && L >= 0 && V > 1);
+    if (L == 0) return LAS_OK;
+    las_dec_state& s = *st_;
+    hipStream_t st = (hipStream_t)stream;
+    bool all_teacher_dummy_; (void)all_teacher_dummy_;
+    bool all_teacher = true;
+    if (step_mode) for (int t = 0; t < L; ++t) if (step_mode[t] != 1) all_teacher = false;
+    LAS_CHECK_ARG(!all_teacher || (y && Ly >= L));
+    LAS_CHECK_ARG(!y || Ly >= L);
+    LAS_CHECK_ARG(all_teacher || (p->w_char && p->b_char && s.logits_step));
+    const long XI = C + E, BC = (long)B * C;
+    // zero initial states (reference asr.py:338-340)
+    for (int l = 0; l < NL; ++l) {
+        LAS_HIP(hipMemsetAsync(s.hs + (long)l * (L + 1) * BC, 0, sizeof(float) * BC, st));
+        LAS_HIP(hipMemsetAsync(s.cs + (long)l * (L + 1) * BC, 0, sizeof(float) * BC, st));
+    }
+    if (loc) { hipLaunchKernelGGL(uniform_att_kernel, dim3(B), dim3(256), 0, st, enc_len, Tp, s.att); LAS_LAUNCH_OK(); }
+    // embeddings of the teacher tokens for every step (step 0 feeds y[:,0] = <sos>)
+    if (y) {
+        hipLaunchKernelGGL(embed_rows_kernel, dim3(L * B), dim3(256), 0, st, p->emb, (const long long*)y, Ly, nullptr, B, C, V,
+                           s.xin, XI, s.tok);
+        LAS_LAUNCH_OK();
+    }
+    const int NCH = att_chunks(Tp), TC = (Tp + NCH - 1) / NCH, ECH = (E + 63) / 64;
+    size_t lds_e = sizeof(float) * (size_t)A;
+    if (loc) lds_e = sizeof(float) * ((size_t)2 * A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + LOC_C * TC);
+    if (lds_e > 64 * 1024) return LAS_E_UNSUPPORTED;
+    const size_t lds_s = sizeof(float) * ((size_t)Tp + 32 + 256);
+    if (lds_s > 64 * 1024) return LAS_E_UNSUPPORTED;
+    for (int t = 0; t < L; ++t) {
+        const float* h0_prev = s.hs + (long)t * BC;                           // layer 0, slot t = h_{t-1}
+        float* q_t = s.q + (long)t * B * A;
+        int rc = las_skinny_launch(prec, h0_prev, C, p->w_phi, C, C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0,
+                                   B, A, nullptr, nullptr, 1, q_t, A, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
+        if (rc) return rc;
+        AttArgs a{};
+        a.B = B; a.Tp = Tp; a.E = E; a.A = A; a.loc = loc; a.TC = TC;
+        a.psi = psi; a.enc = enc; a.lens = enc_len; a.q = q_t;
+        a.prev = s.att + (long)t * B * Tp;
+        a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e; a.b_e = p->b_e;
+        a.e = s.ebuf;
+        a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
+        a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
+        if (loc) hipLaunchKernelGGL(att_energy_fwd<true>, dim3(NCH, B), dim3(256), lds_e, st, a);
+        else hipLaunchKernelGGL(att_energy_fwd<false>, dim3(NCH, B), dim3(256), lds_e, st, a);
+        LAS_LAUNCH_OK();
+        float* xin_t = s.xin + (long)t * B * XI;
+        hipLaunchKernelGGL(att_softmax_ctx, dim3(ECH, B), dim3(256), lds_s, st, Tp, E, s.ebuf, enc, enc_len,
+                           s.att + (long)(t + 1) * B * Tp, xin_t + C, XI);
+        LAS_LAUNCH_OK();
+        // feedback token for this step's input if it is not the teacher's (decided after step t-1's logits)
+        if (t > 0 && step_mode && step_mode[t] != 1) {
+            const float* htop = s.hs + ((long)(NL - 1) * (L + 1) + t) * BC;   // h_top of step t-1
+            rc = las_skinny_launch(prec, htop, C, p->w_char, C, C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, B, V,
+                                   p->b_char, nullptr, 0, s.logits_step, V, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(pick_token_kernel, dim3(B), dim3(256), 0, st, s.logits_step, V, step_mode[t] == 2 ? 1 : 0,
+                               seed + 0x9e3779b9u * (unsigned)t, s.tok + (long)t * B);
+            LAS_LAUNCH_OK();
+            hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, st, p->emb, nullptr, 0, s.tok + (long)t * B, B, C, V,
+                               xin_t, XI, nullptr);
+            LAS_LAUNCH_OK();
+        } else if (t == 0 && !y) {
+            // no teacher at all: <sos> = 0
+            LAS_HIP(hipMemsetAsync(s.tok, 0, sizeof(int32_t) * B, st));
+            hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, st, p->emb, nullptr, 0, s.tok, B, C, V, xin_t, XI, nullptr);
+            LAS_LAUNCH_OK();
+        }
+        // LSTM cells (reference asr.py:352-357; dropout 0)
+        for (int l = 0; l < NL; ++l) {
+            const float* x = l == 0 ? xin_t : s.hs + ((long)(l - 1) * (L + 1) + t + 1) * BC;
+            const int Kx = l == 0 ? (int)XI : C;
+            const float* hp = s.hs + ((long)l * (L + 1) + t) * BC;
+            const float* cp = s.cs + ((long)l * (L + 1) + t) * BC;
+            rc = las_skinny_launch(prec, x, Kx, p->w_ih[l], Kx, Kx, hp, C, p->w_hh[l], C, C, nullptr, 0, nullptr, 0, 0, B, 4 * C,
+                                   p->b_ih[l], p->b_hh[l], 2, nullptr, 0, 0, C, cp, s.hs + ((long)l * (L + 1) + t + 1) * BC,
+                                   s.cs + ((long)l * (L + 1) + t + 1) * BC, s.gates + ((long)l * L + t) * B * 4 * C, st);
+            if (rc) return rc;
+        }
+    }
+    return LAS_OK;
+}

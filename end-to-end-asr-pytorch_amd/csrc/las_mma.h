@@ -1,0 +1,62 @@
+// Shared MFMA helpers for the skinny (M = batch <= 128) products of the recurrent kernels.
+#pragma once
+#include "las_common.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// Operand ("compute") type per precision mode.
+template <int PREC> struct CT;
+template <> struct CT<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int VEC = 8; static constexpr int KSTEP = 32; };
+template <> struct CT<LAS_PREC_F32>  { typedef float  T; static constexpr int VEC = 4; static constexpr int KSTEP = 16; };
+
+template <typename T> __device__ __forceinline__ T to_ct(float f);
+template <> __device__ __forceinline__ bf16_t to_ct<bf16_t>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ float to_ct<float>(float f) { return f; }
+
+// acc[bt] += A(rows bt*16 + (lane&15), k) * B(row (lane&15), k) over k-steps [0, nks); both operands live in
+// LDS as [row][k] (k contiguous).  16x16 MFMA tiles: A rows = batch, B rows = output columns.
+// C/D layout of acc[bt][r]: column = lane&15, row = bt*16 + (lane>>4)*4 + r.
+template <int PREC, int NB>
+__device__ __forceinline__ void mma_rows(f32x4 (&acc)[NB], const typename CT<PREC>::T* __restrict__ Al, int lda,
+                                         const typename CT<PREC>::T* __restrict__ Bl, int ldb, int nks) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    if constexpr (PREC == LAS_PREC_BF16) {
+        for (int ks = 0; ks < nks; ++ks) {
+            const bf16x8 b = *(const bf16x8*)(Bl + fr * ldb + ks * 32 + fq * 8);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                const bf16x8 a = *(const bf16x8*)(Al + (bt * 16 + fr) * lda + ks * 32 + fq * 8);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[bt], 0, 0, 0);
+            }
+        }
+    } else {
+        for (int ks = 0; ks < nks; ++ks) {        // lane holds k = 16*ks + 4*fq + {0..3}; MFMA j uses element j
+            const float4 b = *(const float4*)(Bl + fr * ldb + ks * 16 + fq * 4);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                const float4 a = *(const float4*)(Al + (bt * 16 + fr) * lda + ks * 16 + fq * 4);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[bt], 0, 0, 0);
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[bt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// tanh through one v_exp: |abs err| ~1e-7, used where the argument is already O(1) noise-limited.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(2.f * x);
+    return 1.f - 2.f / (e + 1.f);
+}
+
+inline int las_pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
+
+#define LAS_NB_SWITCH(NBV, CALL)                        \
+    switch (NBV) {                                      \
+        case 1: { constexpr int NB_ = 1; CALL; } break; \
+        case 2: { constexpr int NB_ = 2; CALL; } break; \
+        case 4: { constexpr int NB_ = 4; CALL; } break; \
+        case 8: { constexpr int NB_ = 8; CALL; } break; \
+        default: return LAS_E_UNSUPPORTED;              \
+    }

@@ -22,19 +22,13 @@
 //     enforced by the LDS request.  Spins are bounded; a timeout sets *status and every workgroup exits.
 //   * the published history doubles as the saved activations for BPTT.
 // Backward mirrors this with dgates[B,4H] as the exchanged quantity and W_hh^T columns resident.
-#include "las_common.h"
+#include "las_mma.h"
 
 namespace {
 
 constexpr int NT = 256;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr size_t MIN_LDS = 84 * 1024;            // > 80 KiB: at most one workgroup per CU
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-template <int PREC> struct CT;
-template <> struct CT<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int VEC = 8; static constexpr int KSTEP = 32; };
-template <> struct CT<LAS_PREC_F32>  { typedef float  T; static constexpr int VEC = 4; static constexpr int KSTEP = 16; };
 
 struct SyncWords {          // zeroed by hipMemsetAsync before every launch
     unsigned cnt[2];        // arrivals per direction
@@ -96,35 +90,6 @@ __device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int row
     }
 }
 
-// acc[bt] += A(tile rows bt*16.., k) * B(rows of Wrow.., k) over k-steps [ks0, ks1)
-template <int PREC, int NB>
-__device__ __forceinline__ void mma_rows(f32x4 (&acc)[NB], const typename CT<PREC>::T* __restrict__ Al,
-                                         const typename CT<PREC>::T* __restrict__ Bl, int ld, int ks0, int ks1) {
-    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
-    if constexpr (PREC == LAS_PREC_BF16) {
-        for (int ks = ks0; ks < ks1; ++ks) {
-            const bf16x8 b = *(const bf16x8*)(Bl + fr * ld + ks * 32 + fq * 8);
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                const bf16x8 a = *(const bf16x8*)(Al + (bt * 16 + fr) * ld + ks * 32 + fq * 8);
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[bt], 0, 0, 0);
-            }
-        }
-    } else {
-        for (int ks = ks0; ks < ks1; ++ks) {
-            const float4 b = *(const float4*)(Bl + fr * ld + ks * 16 + fq * 4);
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                const float4 a = *(const float4*)(Al + (bt * 16 + fr) * ld + ks * 16 + fq * 4);
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[bt], 0, 0, 0);
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[bt], 0, 0, 0);
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[bt], 0, 0, 0);
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[bt], 0, 0, 0);
-            }
-        }
-    }
-}
-
 struct LstmArgs {
     int T, B, H, ND, U, G;
     int sr, concat, T_out, F_out;
@@ -153,6 +118,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, B = a.B, U = a.U, ND = a.ND;
     const int Kp = (H + KSTEP - 1) / KSTEP * KSTEP, ld = Kp + VEC;
+    const int Hx = (H + VEC - 1) / VEC * VEC;           // exchange row stride (pad columns are caller-zeroed)
     const int d = blockIdx.x / a.G, g = blockIdx.x % a.G, j0 = g * U;
     T* Wl = (T*)smem;                                   // [4][16][ld]
     T* Hl = Wl + 4 * 16 * ld;                           // [NB*16][ld]
@@ -210,14 +176,14 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
         if (s > 0) {
             if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            pull_tile_sc1<T, VEC>(hx + ((long)d * a.T + tp) * B * H, B, H, Hl, ld);
+            pull_tile_sc1<T, VEC>(hx + ((long)d * a.T + tp) * B * Hx, B, Hx, Hl, ld);
         }
         __syncthreads();
         // (d) gate pre-activations: wave w <-> gate w
         f32x4 acc[NB];
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) mma_rows<PREC, NB>(acc, Hl, Wl + wave * 16 * ld, ld, 0, Kp / KSTEP);
+        if (s > 0) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
         // (e) accumulators -> LDS  (C/D layout: col = lane&15 = unit, row = (lane>>4)*4 + r = batch)
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt)
@@ -245,7 +211,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
                 hv[q] = mq ? hn : 0.f;
                 gv[0][q] = mq ? ig : 0.f; gv[1][q] = mq ? fg : 0.f; gv[2][q] = mq ? gg : 0.f; gv[3][q] = mq ? og : 0.f;
             }
-            st_pair_sc1(hx + (((long)d * a.T + t) * B + b) * H + j, hv[0], hv[1]);
+            st_pair_sc1(hx + (((long)d * a.T + t) * B + b) * Hx + j, hv[0], hv[1]);
             const long ro = (long)t * B + b;
             *(float2*)(hf + ro * (ND * H) + d * H + j) = make_float2(hv[0], hv[1]);
             if (!a.y_is_hf) {
@@ -357,32 +323,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
                 }
                 __syncthreads();
                 // A = Dl rows (batch) x k ; B = Wl rows (unit) x k, offset to this chunk/wave quarter
-                {
-                    const T* Ab = Dl + wave * kq * KSTEP;
-                    const T* Bb = Wl + c * KC + wave * kq * KSTEP;
-                    if constexpr (PREC == LAS_PREC_BF16) {
-                        for (int ks = 0; ks < kq; ++ks) {
-                            const bf16x8 bv = *(const bf16x8*)(Bb + fr * ldw + ks * 32 + fq * 8);
-#pragma unroll
-                            for (int bt = 0; bt < NB; ++bt) {
-                                const bf16x8 av = *(const bf16x8*)(Ab + (bt * 16 + fr) * ldc + ks * 32 + fq * 8);
-                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[bt], 0, 0, 0);
-                            }
-                        }
-                    } else {
-                        for (int ks = 0; ks < kq; ++ks) {
-                            const float4 bv = *(const float4*)(Bb + fr * ldw + ks * 16 + fq * 4);
-#pragma unroll
-                            for (int bt = 0; bt < NB; ++bt) {
-                                const float4 av = *(const float4*)(Ab + (bt * 16 + fr) * ldc + ks * 16 + fq * 4);
-                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[bt], 0, 0, 0);
-                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[bt], 0, 0, 0);
-                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[bt], 0, 0, 0);
-                                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[bt], 0, 0, 0);
-                            }
-                        }
-                    }
-                }
+                mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);
             }
         }
 #pragma unroll
@@ -442,12 +383,11 @@ size_t bwd_lds(int prec, int H, int NB, int NC) {
 }
 constexpr size_t LDS_CAP = 160 * 1024;
 
-int pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
 
 int check_common(int T, int B, int H, int ND, int sr) {
     if (T <= 0 || B <= 0 || H <= 0 || (ND != 1 && ND != 2) || sr < 1) return LAS_E_BADARG;
-    if (H % 8 != 0) return LAS_E_UNSUPPORTED;          // 16-byte exchange vectors / pair stores
-    if (pick_nb(B) == 0) return LAS_E_UNSUPPORTED;
+    if (H % 2 != 0) return LAS_E_UNSUPPORTED;          // pair stores / float2 accesses
+    if (las_pick_nb(B) == 0) return LAS_E_UNSUPPORTED;
     return LAS_OK;
 }
 
@@ -483,14 +423,6 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
     return LAS_OK;
 }
 
-#define LAS_NB_SWITCH(NBV, CALL)            \
-    switch (NBV) {                          \
-        case 1: { constexpr int NB_ = 1; CALL; } break; \
-        case 2: { constexpr int NB_ = 2; CALL; } break; \
-        case 4: { constexpr int NB_ = 4; CALL; } break; \
-        case 8: { constexpr int NB_ = 8; CALL; } break; \
-        default: return LAS_E_UNSUPPORTED;  \
-    }
 
 }  // namespace
 
@@ -508,7 +440,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     LAS_CHECK_ARG(xproj && b_ih && b_hh && w_hh && lens && y && hf && hx && gates && cs && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
-    const int NB = pick_nb(B);
+    const int NB = las_pick_nb(B);
     int U = 16;
     size_t lds = fwd_lds(prec, H, NB);
     if (lds > LDS_CAP || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
@@ -535,7 +467,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     LAS_CHECK_ARG(dy && gates && cs && w_hh && lens && dgx && dgf && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
-    const int NB = pick_nb(B);
+    const int NB = las_pick_nb(B);
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     const int ks = prec == LAS_PREC_BF16 ? 32 : 16;
     const int K4p = bwd_k4p(prec, H);

@@ -59,6 +59,19 @@ __global__ __launch_bounds__(64) void count_nonzero_i64_kernel(const long long* 
     if (threadIdx.x == 0) out[b] = (int)c;
 }
 
+
+// out[c][r] = in[r][c], 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                          int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = in[(long)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) out[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
 }  // namespace
 
 extern "C" int las_transpose01(const float* in, float* out, int D0, int D1, int F, void* stream) {
@@ -89,6 +102,13 @@ extern "C" int las_infer_lengths(const float* x, int B, int T, int D, int32_t* l
 extern "C" int las_count_nonzero_i64(const int64_t* y, int B, int L, int32_t* out, void* stream) {
     LAS_CHECK_ARG(y && out && B > 0 && L > 0);
     hipLaunchKernelGGL(count_nonzero_i64_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)y, L, out);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_transpose2d(const float* in, float* out, int R, int C, void* stream) {
+    LAS_CHECK_ARG(in && out && R > 0 && C > 0);
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

@@ -1,0 +1,210 @@
+// Skinny MFMA product for the per-step decoder matmuls (M = batch <= 128), with fused epilogues.
+//
+//   pre[b][n] = sum_s sum_k X_s[b][k] * W_s[row(n)][k]  (+ bias0[row] + bias1[row])
+//
+// Replaces, one decode step at a time: nn.LSTMCell (reference src/asr.py:329-331, called :353-355:
+// gates = W_ih x + b_ih + W_hh h + b_hh followed by the cell pointwise), tanh(phi(h)) (:383,422), the
+// per-step char_trans when sampling (:92), and in backward the dgates*W products (with transposed weight
+// copies so every operand row is k-contiguous).
+//
+// One workgroup = 16 output columns x all batch rows; K is split over the 4 waves (partials meet in LDS).
+// Operands are staged fp32 -> operand type into LDS as [row][k]; up to 3 (X,W) segments are concatenated
+// along k (e.g. [emb|ctx] with W_ih and h with W_hh).  Epilogues: store (+accumulate), tanh, LSTM cell.
+#include "las_mma.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Seg {
+    const float* x; long ldx;
+    const float* w; long ldw;
+    int K;
+};
+struct SkinnyArgs {
+    Seg seg[3];
+    int ns, B, N;
+    const float* bias0; const float* bias1;
+    int mode;                 // 0 store, 1 tanh, 2 lstm cell
+    float* out; long ldo; int accumulate;
+    // cell mode: N = 4*C gate rows (i,f,g,o blocks of C); tile column c -> gate c>>2, unit blk*4 + (c&3)
+    int C;
+    const float* c_prev; float* h_out; float* c_out; float* gates_out;
+};
+
+// Copy n source floats (converted) to dst; float4 path when both sides allow it.
+template <typename T>
+__device__ __forceinline__ void stage_piece(T* __restrict__ dst, const float* __restrict__ src, int n, int lane) {
+    const bool vec = ((n & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+    if (vec) {
+        for (int i = lane; i < n / 4; i += 64) {
+            const float4 v = ((const float4*)src)[i];
+            dst[i * 4 + 0] = to_ct<T>(v.x); dst[i * 4 + 1] = to_ct<T>(v.y);
+            dst[i * 4 + 2] = to_ct<T>(v.z); dst[i * 4 + 3] = to_ct<T>(v.w);
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) dst[i] = to_ct<T>(src[i]);
+    }
+}
+
+// One LDS row of k-chunk [k0, k0+KC) of the concatenated, per-segment-padded k axis.
+template <typename T>
+__device__ __forceinline__ void stage_chunk_row(T* __restrict__ d, const SkinnyArgs& a, const int (&koff)[4], int k0,
+                                                int KC, long row, bool is_w, bool valid, int lane) {
+    for (int i = lane; i < KC; i += 64) d[i] = (T)0;
+    if (!valid) return;
+    for (int s = 0; s < a.ns; ++s) {
+        const int lo = max(k0, koff[s]), hi = min(k0 + KC, koff[s] + a.seg[s].K);
+        if (hi <= lo) continue;
+        const float* src = (is_w ? a.seg[s].w + row * a.seg[s].ldw : a.seg[s].x + row * a.seg[s].ldx) + (lo - koff[s]);
+        stage_piece<T>(d + (lo - k0), src, hi - lo, lane);
+    }
+}
+
+template <int PREC, int NB>
+__global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NCK) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // k layout: each segment padded to KSTEP; walked in NCK chunks of KC (KC % (4*KSTEP) == 0)
+    int koff[4];
+    koff[0] = 0;
+    for (int s = 0; s < 3; ++s) koff[s + 1] = koff[s] + (s < a.ns ? (a.seg[s].K + KSTEP - 1) / KSTEP * KSTEP : 0);
+    const int ld = KC + VEC;
+    T* Al = (T*)smem;                         // [NB*16][ld]
+    T* Bl = Al + NB * 16 * ld;                // [16][ld]
+    float* Gl = (float*)(Bl + 16 * ld);       // [4][NB*16][17]
+    const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    // W row of tile column c
+    auto wrow = [&](int c) -> int {
+        if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
+        const int n = blk * 16 + c;
+        return n < a.N ? n : -1;
+    };
+    const int q = KC / KSTEP / 4;             // k-steps per wave per chunk
+    f32x4 acc[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ck = 0; ck < NCK; ++ck) {
+        if (ck > 0) __syncthreads();
+        // stage A (batch rows) and B (weight rows): one wave per row, round robin
+        for (int r = wave; r < NB * 16; r += 4) stage_chunk_row<T>(Al + r * ld, a, koff, ck * KC, KC, r, false, r < a.B, lane);
+        for (int c = wave; c < 16; c += 4) {
+            const int row = wrow(c);
+            stage_chunk_row<T>(Bl + c * ld, a, koff, ck * KC, KC, row, true, row >= 0, lane);
+        }
+        __syncthreads();
+        mma_rows<PREC, NB>(acc, Al + wave * q * KSTEP, ld, Bl + wave * q * KSTEP, ld, q);
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
+    __syncthreads();
+    // ---- epilogue
+    if (a.mode != 2) {
+        for (int e = threadIdx.x; e < a.B * 16; e += NT) {
+            const int b = e >> 4, c = e & 15, row = wrow(c);
+            if (row < 0) continue;
+            float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] + Gl[(2 * NB * 16 + b) * 17 + c] +
+                      Gl[(3 * NB * 16 + b) * 17 + c];
+            if (a.bias0) v += a.bias0[row];
+            if (a.bias1) v += a.bias1[row];
+            float* o = a.out + (long)b * a.ldo + row;
+            if (a.accumulate) v += *o;
+            if (a.mode == 1) v = tanhf(v);
+            *o = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < a.B * 4; e += NT) {
+            const int b = e >> 2, jj = e & 3, u = blk * 4 + jj;
+            if (u >= a.C) continue;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = g * 4 + jj, row = g * a.C + u;
+                float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] +
+                          Gl[(2 * NB * 16 + b) * 17 + c] + Gl[(3 * NB * 16 + b) * 17 + c];
+                if (a.bias0) v += a.bias0[row];
+                if (a.bias1) v += a.bias1[row];
+                pre[g] = v;
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float cn = fg * a.c_prev[(long)b * a.C + u] + ig * gg;
+            a.c_out[(long)b * a.C + u] = cn;
+            a.h_out[(long)b * a.C + u] = og * tanhf(cn);
+            float* go = a.gates_out + (long)b * 4 * a.C;
+            go[u] = ig; go[a.C + u] = fg; go[2 * a.C + u] = gg; go[3 * a.C + u] = og;
+        }
+    }
+}
+
+constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU
+
+// choose the k-chunking: returns LDS bytes, sets KC and NCK
+size_t skinny_plan(int prec, const SkinnyArgs& a, int NB, int& KC, int& NCK) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ks = prec == LAS_PREC_BF16 ? 32 : 16;
+    int k = 0;
+    for (int s = 0; s < a.ns; ++s) k += (a.seg[s].K + ks - 1) / ks * ks;
+    const int quantum = 4 * ks;
+    const size_t fixed = sizeof(float) * 4 * NB * 16 * 17;
+    for (NCK = 1;; ++NCK) {
+        KC = ((k + NCK - 1) / NCK + quantum - 1) / quantum * quantum;
+        const size_t lds = (size_t)(NB * 16 + 16) * (KC + vec) * sz + fixed;
+        if (lds <= SKINNY_LDS_TARGET || KC == quantum) return lds;
+    }
+}
+
+template <int PREC, int NB>
+int launch(const SkinnyArgs& a, size_t lds, int KC, int NCK, int grid, hipStream_t st) {
+    auto k = skinny_kernel<PREC, NB>;
+    if (lds > 64 * 1024) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a, KC, NCK);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+}  // namespace
+
+// Internal C++ entry used by the decoder driver (decoder.hip) and by the public wrappers below.
+int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                      long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                      long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                      long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                      float* gates_out, hipStream_t st) {
+    SkinnyArgs a{};
+    a.seg[0] = Seg{x0, ldx0, w0, ldw0, K0};
+    a.seg[1] = Seg{x1, ldx1, w1, ldw1, K1};
+    a.seg[2] = Seg{x2, ldx2, w2, ldw2, K2};
+    a.ns = x2 ? 3 : (x1 ? 2 : 1);
+    a.B = B; a.N = N; a.bias0 = bias0; a.bias1 = bias1; a.mode = mode; a.out = out; a.ldo = ldo;
+    a.accumulate = accumulate; a.C = C; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.gates_out = gates_out;
+    const int NB = las_pick_nb(B);
+    if (NB == 0 || B <= 0 || N <= 0 || K0 <= 0) return LAS_E_UNSUPPORTED;
+    if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
+    int KC = 0, NCK = 0;
+    const size_t lds = skinny_plan(prec, a, NB, KC, NCK);
+    if (lds > 160 * 1024) return LAS_E_UNSUPPORTED;
+    const int grid = mode == 2 ? (C + 3) / 4 : (N + 15) / 16;
+    if (prec == LAS_PREC_BF16) { LAS_NB_SWITCH(NB, return (launch<LAS_PREC_BF16, NB_>(a, lds, KC, NCK, grid, st))); }
+    else { LAS_NB_SWITCH(NB, return (launch<LAS_PREC_F32, NB_>(a, lds, KC, NCK, grid, st))); }
+    return LAS_E_BADARG;
+}
+
+extern "C" int las_lstm_cell_fwd(int prec, const float* x, int64_t ldx, int Kx, const float* h_prev, const float* c_prev,
+                                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int B, int C,
+                                 float* h_out, float* c_out, float* gates_out, void* stream) {
+    LAS_CHECK_ARG(x && h_prev && c_prev && w_ih && w_hh && h_out && c_out && gates_out && B > 0 && C > 0 && Kx > 0);
+    return las_skinny_launch(prec, x, ldx, w_ih, Kx, Kx, h_prev, C, w_hh, C, C, nullptr, 0, nullptr, 0, 0, B, 4 * C, b_ih,
+                             b_hh, 2, nullptr, 0, 0, C, c_prev, h_out, c_out, gates_out, (hipStream_t)stream);
+}
+
+extern "C" int las_skinny_linear(int prec, const float* x, int64_t ldx, const float* w, int64_t ldw, int B, int N, int K,
+                                 const float* bias, int act, int accumulate, float* out, int64_t ldo, void* stream) {
+    LAS_CHECK_ARG(x && w && out && B > 0 && N > 0 && K > 0);
+    return las_skinny_launch(prec, x, ldx, w, ldw, K, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, B, N, bias,
+                             nullptr, act ? 1 : 0, out, ldo, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
+                             (hipStream_t)stream);
+}

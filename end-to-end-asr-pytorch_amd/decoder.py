@@ -1,0 +1,204 @@
+"""Host side of the attend-and-spell decoder loop: ctypes mirrors of las_dec_* (include/las_hip.h) and the
+autograd Function that runs all L steps (and their BPTT) behind two C-ABI calls."""
+import ctypes
+import torch
+
+from . import _lib, ops
+from ._lib import P, I, ptr, check, cur_stream
+
+LOC_C, LOC_W = 10, 201
+
+
+class DecDims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ('B', 'Tp', 'E', 'A', 'C', 'NL', 'V', 'L', 'loc', 'prec')]
+
+
+class DecParams(ctypes.Structure):
+    _fields_ = [('emb', P), ('w_phi', P), ('conv_w', P), ('w_lp', P), ('w_e', P), ('b_e', P),
+                ('w_ih', P * 4), ('w_hh', P * 4), ('b_ih', P * 4), ('b_hh', P * 4), ('w_char', P), ('b_char', P),
+                ('w_ihT', P * 4), ('w_hhT', P * 4), ('w_phiT', P)]
+
+
+class DecState(ctypes.Structure):
+    _fields_ = [('tok', P), ('xin', P), ('q', P), ('att', P), ('hs', P), ('cs', P), ('gates', P), ('f', P), ('s', P),
+                ('ebuf', P), ('logits_step', P)]
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def make_params(W, NL, loc, transposed=None):
+    """W: dict of contiguous fp32 HIP tensors with the reference's parameter names."""
+    p = DecParams()
+    p.emb, p.w_phi = _p(W['embed.weight']), _p(W['attention.phi.weight'])
+    if loc:
+        p.conv_w, p.w_lp = _p(W['attention.loc_conv.weight']), _p(W['attention.loc_proj.weight'])
+        p.w_e, p.b_e = _p(W['attention.gen_energy.weight']), _p(W['attention.gen_energy.bias'])
+    for l in range(NL):
+        p.w_ih[l], p.w_hh[l] = _p(W[f'decoder.layer{l}.weight_ih']), _p(W[f'decoder.layer{l}.weight_hh'])
+        p.b_ih[l], p.b_hh[l] = _p(W[f'decoder.layer{l}.bias_ih']), _p(W[f'decoder.layer{l}.bias_hh'])
+    p.w_char, p.b_char = _p(W['char_trans.weight']), _p(W['char_trans.bias'])
+    if transposed is not None:
+        for l in range(NL):
+            p.w_ihT[l], p.w_hhT[l] = _p(transposed[f'ih{l}']), _p(transposed[f'hh{l}'])
+        p.w_phiT = _p(transposed['phi'])
+    return p
+
+
+def alloc_state(dims, dev):
+    d = dims
+    f32 = dict(dtype=torch.float32, device=dev)
+    S = dict(
+        tok=torch.empty(d.L, d.B, dtype=torch.int32, device=dev),
+        xin=torch.empty(d.L, d.B, d.C + d.E, **f32),
+        q=torch.empty(d.L, d.B, d.A, **f32),
+        att=torch.empty(d.L + 1, d.B, d.Tp, **f32),
+        hs=torch.empty(d.NL, d.L + 1, d.B, d.C, **f32),
+        cs=torch.empty(d.NL, d.L + 1, d.B, d.C, **f32),
+        gates=torch.empty(d.NL, d.L, d.B, 4 * d.C, **f32),
+        ebuf=torch.empty(d.B, d.Tp, **f32),
+        logits_step=torch.empty(d.B, d.V, **f32),
+    )
+    if d.loc:
+        S['f'] = torch.empty(d.L, d.B, LOC_C, d.Tp, **f32)
+        S['s'] = torch.empty(d.L, d.B, d.Tp, d.A, **f32)
+    st = DecState()
+    for k, v in S.items():
+        setattr(st, k, v.data_ptr())
+    return S, st
+
+
+def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, seed=0):
+    """Runs las_decoder_fwd; returns the dict of saved-state tensors (used by tests and by DecoderFn)."""
+    L_ = _lib.lib()
+    B, Tp, E = enc.shape
+    A = psi.shape[-1]
+    V, C = W['embed.weight'].shape
+    dims = DecDims(B, Tp, E, A, C, NL, V, L, int(loc), ops._prec)
+    params = make_params(W, NL, loc)
+    S, st = alloc_state(dims, enc.device)
+    sm = None
+    if step_mode is not None:
+        sm = (ctypes.c_uint8 * L)(*[int(v) for v in step_mode])
+    check(L_.las_decoder_fwd(ctypes.byref(dims), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                             ptr(y) if y is not None else None, I(y.shape[1] if y is not None else 0), sm,
+                             ctypes.c_uint(seed & 0xffffffff), ctypes.byref(st), cur_stream()), 'las_decoder_fwd')
+    S['_dims'], S['_keep'] = dims, (params, st)
+    return S
+
+
+class DecBwdState(ctypes.Structure):
+    _fields_ = [(n, P) for n in ('dgates', 'dxin', 'dq_pre', 'de', 'dh_carry', 'dc_carry', 'd_below', 'da', 'extra',
+                                 'dpsi', 'acc', 'demb')]
+
+
+def transpose2d(w):
+    L_ = _lib.lib()
+    w = w.contiguous()
+    R, Cc = w.shape
+    out = torch.empty(Cc, R, dtype=torch.float32, device=w.device)
+    check(L_.las_transpose2d(ptr(w), ptr(out), I(R), I(Cc), cur_stream()), 'las_transpose2d')
+    return out
+
+
+WNAMES_BASE = ['embed.weight', 'attention.phi.weight']
+WNAMES_LOC = ['attention.loc_conv.weight', 'attention.loc_proj.weight', 'attention.gen_energy.weight',
+              'attention.gen_energy.bias']
+
+
+def weight_names(NL, loc):
+    n = list(WNAMES_BASE) + (list(WNAMES_LOC) if loc else [])
+    for l in range(NL):
+        n += [f'decoder.layer{l}.weight_ih', f'decoder.layer{l}.weight_hh', f'decoder.layer{l}.bias_ih',
+              f'decoder.layer{l}.bias_hh']
+    return n + ['char_trans.weight', 'char_trans.bias']
+
+
+class DecoderFn(torch.autograd.Function):
+    """All L attend-and-spell steps (reference asr.py:77-107) and their BPTT.
+    forward(enc [B,T',E], psi [B,T',A], enc_len i32 [B], y i64 [B,Ly] | None, L, NL, loc, step_mode, seed, *weights)
+      -> h_top [L,B,C] (time-major top-layer states), att [L,B,T'] (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, *weights):
+        names = weight_names(NL, loc)
+        W = dict(zip(names, weights))
+        enc, psi = enc.contiguous(), psi.contiguous()
+        S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed)
+        ctx.S, ctx.W, ctx.cfg = S, W, (L, NL, loc, names)
+        ctx.save_for_backward(enc, psi, enc_len)
+        h_top = S['hs'][NL - 1, 1:]
+        att = S['att'][1:]
+        ctx.mark_non_differentiable(att)
+        return h_top, att
+
+    @staticmethod
+    def backward(ctx, g_htop, _g_att):
+        L_ = _lib.lib()
+        enc, psi, enc_len = ctx.saved_tensors
+        S, W = ctx.S, ctx.W
+        L, NL, loc, names = ctx.cfg
+        d = S['_dims']
+        dev = enc.device
+        B, Tp, E, A, C, V = d.B, d.Tp, d.E, d.A, d.C, d.V
+        f32 = dict(dtype=torch.float32, device=dev)
+        tr = {'phi': transpose2d(W['attention.phi.weight'])}
+        for l in range(NL):
+            tr[f'ih{l}'] = transpose2d(W[f'decoder.layer{l}.weight_ih'])
+            tr[f'hh{l}'] = transpose2d(W[f'decoder.layer{l}.weight_hh'])
+        params = make_params(W, NL, loc, tr)
+        nch = L_.las_decoder_att_chunks(I(Tp))
+        accf = L_.las_decoder_loc_acc_floats(I(A))
+        Bw = dict(dgates=torch.empty(NL, L, B, 4 * C, **f32), dxin=torch.empty(L, B, C + E, **f32),
+                  dq_pre=torch.empty(L, B, A, **f32), dh_carry=torch.empty(NL, B, C, **f32),
+                  dc_carry=torch.empty(NL, B, C, **f32), d_below=torch.empty(B, C, **f32), da=torch.empty(B, Tp, **f32),
+                  demb=torch.empty(V, C, **f32))
+        if loc:
+            Bw.update(extra=torch.empty(2, B, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
+                      acc=torch.empty(B * nch, accf, **f32))
+        else:
+            Bw['de'] = torch.empty(L, B, Tp, **f32)
+        bw = DecBwdState()
+        for k, v in Bw.items():
+            setattr(bw, k, v.data_ptr())
+        st = S['_keep'][1]
+        g_htop = g_htop.contiguous()
+        check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                                 ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
+        # ---- contractions over the L steps: one GEMM each
+        LB = L * B
+        XI = C + E
+        g = {}
+        g['embed.weight'] = Bw['demb']
+        hs0_prev = S['hs'][0, :L].reshape(LB, C)
+        g['attention.phi.weight'] = ops.gemm(Bw['dq_pre'].view(LB, A), hs0_prev, transA=True)
+        for l in range(NL):
+            dg = Bw['dgates'][l].view(LB, 4 * C)
+            x_l = S['xin'].view(LB, XI) if l == 0 else S['hs'][l - 1, 1:].reshape(LB, C)
+            g[f'decoder.layer{l}.weight_ih'] = ops.gemm(dg, x_l, transA=True)
+            g[f'decoder.layer{l}.weight_hh'] = ops.gemm(dg, S['hs'][l, :L].reshape(LB, C), transA=True)
+            gb = ops.colsum(dg, torch.empty(4 * C, **f32))
+            g[f'decoder.layer{l}.bias_ih'] = gb
+            g[f'decoder.layer{l}.bias_hh'] = gb.clone()
+        # d enc[b] [T',E] = att[:,b]^T [T' x L] * dctx[:,b] [L x E]
+        att = S['att'][1:]
+        d_enc = torch.empty(B, Tp, E, **f32)
+        ops.gemm(att, Bw['dxin'][:, :, C:], d_enc, transA=True, M=Tp, N=E, K=L, lda=B * Tp, ldb=B * XI, ldc=E,
+                 batch=B, sA=Tp, sB=XI, sC=Tp * E)
+        if loc:
+            d_psi = Bw['dpsi']
+            acc = Bw['acc']
+            red = ops.colsum(acc, torch.empty(accf, **f32))
+            off = ((A * 10 + A + 1 + 3) // 4) * 4
+            g['attention.loc_proj.weight'] = red[:A * 10].view(A, 10)
+            g['attention.gen_energy.weight'] = red[A * 10:A * 10 + A].view(1, A)
+            g['attention.gen_energy.bias'] = red[A * 10 + A:A * 10 + A + 1]
+            g['attention.loc_conv.weight'] = red[off:off + 10 * 201].view(10, 1, 201)
+        else:
+            d_psi = torch.empty(B, Tp, A, **f32)
+            ops.gemm(Bw['de'], S['q'], d_psi, transA=True, M=Tp, N=A, K=L, lda=B * Tp, ldb=B * A, ldc=A, batch=B,
+                     sA=Tp, sB=A, sC=Tp * A)
+        ctx.S = None
+        wg = [g.get(n) for n in names]
+        return (d_enc, d_psi, None, None, None, None, None, None, None, *wg)

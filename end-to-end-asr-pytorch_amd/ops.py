@@ -16,40 +16,48 @@ def _i32(t, device):
 
 
 # ----------------------------------------------------------------------------- CTC
+def _ctc_fwd(logits, label, enc_len, tgt_len, blank):
+    L_ = _lib.lib()
+    B, T, V = logits.shape
+    L = label.shape[1]
+    dev = logits.device
+    label, enc_len, tgt_len = _i32(label, dev), _i32(enc_len, dev), _i32(tgt_len, dev)
+    nbytes = L_.las_ctc_workspace_bytes(I(B), I(T), I(V), I(L))
+    ws = _ws(nbytes, dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    la = torch.empty(B, T, 2 * L + 1, dtype=torch.float32, device=dev)
+    check(L_.las_ctc_loss_fwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
+                              I(blank), ptr(nll), ptr(la), ptr(ws), Z(ws.numel()), cur_stream()),
+          'las_ctc_loss_fwd')
+    return nll, la, (logits, label, enc_len, tgt_len, nll, la, ws, blank)
+
+
+def _ctc_bwd(saved, gscale):
+    L_ = _lib.lib()
+    logits, label, enc_len, tgt_len, nll, la, ws, blank = saved
+    B, T, V = logits.shape
+    L = label.shape[1]
+    grad = torch.empty_like(logits)
+    gs = gscale.contiguous().float()
+    check(L_.las_ctc_loss_bwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
+                              I(blank), ptr(nll), ptr(la), ptr(gs), ptr(grad), ptr(ws), Z(ws.numel()),
+                              cur_stream()), 'las_ctc_loss_bwd')
+    return grad
+
+
 class CTCLossFn(torch.autograd.Function):
     """nll[b], log_alpha = CTC(log_softmax(logits[b]), label[b]); reference src/solver.py:93,160."""
 
     @staticmethod
     def forward(ctx, logits, label, enc_len, tgt_len, blank):
-        L_ = _lib.lib()
-        logits = logits.contiguous()
-        B, T, V = logits.shape
-        L = label.shape[1]
-        dev = logits.device
-        label, enc_len, tgt_len = _i32(label, dev), _i32(enc_len, dev), _i32(tgt_len, dev)
-        nbytes = L_.las_ctc_workspace_bytes(I(B), I(T), I(V), I(L))
-        ws = _ws(nbytes, dev)
-        nll = torch.empty(B, dtype=torch.float32, device=dev)
-        la = torch.empty(B, T, 2 * L + 1, dtype=torch.float32, device=dev)
-        check(L_.las_ctc_loss_fwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
-                                  I(blank), ptr(nll), ptr(la), ptr(ws), Z(ws.numel()), cur_stream()),
-              'las_ctc_loss_fwd')
-        ctx.save_for_backward(logits, label, enc_len, tgt_len, nll, la, ws)
-        ctx.blank = blank
+        nll, la, ctx.saved = _ctc_fwd(logits.contiguous(), label, enc_len, tgt_len, blank)
         ctx.mark_non_differentiable(la)
         return nll, la
 
     @staticmethod
     def backward(ctx, gnll, _gla):
-        L_ = _lib.lib()
-        logits, label, enc_len, tgt_len, nll, la, ws = ctx.saved_tensors
-        B, T, V = logits.shape
-        L = label.shape[1]
-        grad = torch.empty_like(logits)
-        gs = gnll.contiguous().float()
-        check(L_.las_ctc_loss_bwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
-                                  I(ctx.blank), ptr(nll), ptr(la), ptr(gs), ptr(grad), ptr(ws), Z(ws.numel()),
-                                  cur_stream()), 'las_ctc_loss_bwd')
+        grad = _ctc_bwd(ctx.saved, gnll)
+        ctx.saved = None
         return grad, None, None, None, None
 
 
@@ -201,66 +209,164 @@ def lstm_out_shape(T, H, ND, sr, concat):
     return (T + sr - 1) // sr, ND * H
 
 
+def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
+    L_ = _lib.lib()
+    x = x.contiguous()
+    T, B, Iin = x.shape
+    ND, H4, H = w_hh.shape
+    dev = x.device
+    xproj = gemm(x.view(T * B, Iin), w_ih, transB=True)
+    T_out, F_out = lstm_out_shape(T, H, ND, sr, concat)
+    hf = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
+    y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
+    esz, vec = (2, 8) if _prec == 0 else (4, 4)
+    Hx = (H + vec - 1) // vec * vec
+    hx = (torch.empty if Hx == H else torch.zeros)(ND * T * B * Hx * esz, dtype=torch.uint8, device=dev)
+    gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
+    cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
+    sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
+    check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
+                              I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
+                              ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
+    return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec)
+
+
+def _lstm_bwd(saved, gy, need_gx):
+    """-> gx [T,B,I]|None, gw_ih [ND*4H,I], gw_hh [ND,4H,H], gb [ND*4H] (= d b_ih = d b_hh)."""
+    L_ = _lib.lib()
+    x, lens, w_ih, w_hh, hf, gates, cs, status, sr, concat, prec = saved
+    T, B, Iin = x.shape
+    ND, H4, H = w_hh.shape
+    dev = x.device
+    gy = gy.contiguous()
+    esz = 2 if prec == 0 else 4
+    dgx = torch.empty(ND * T * B * H4 * esz, dtype=torch.uint8, device=dev)
+    dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
+    sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
+    check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
+                              I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
+          'las_lstm_rec_bwd')
+    x2 = x.view(T * B, Iin)
+    gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
+    gw_ih = gemm(dgf, x2, transA=True)                                         # [ND*4H, I]
+    gb = colsum(dgf, torch.empty(ND * H4, dtype=torch.float32, device=dev))
+    gw_hh = torch.empty_like(w_hh)
+    hf2 = hf.view(T * B, ND * H)
+    for d in range(ND):
+        if T > 1:
+            if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
+                A, Bm = dgf[B:, d * H4:(d + 1) * H4], hf2[:(T - 1) * B, d * H:(d + 1) * H]
+            else:           # sum_{t<=T-2} dg[t]^T h[t+1]
+                A, Bm = dgf[:(T - 1) * B, d * H4:(d + 1) * H4], hf2[B:, d * H:(d + 1) * H]
+            gemm(A, Bm, gw_hh[d], transA=True)
+        else:
+            gw_hh[d].zero_()
+    return gx, gw_ih, gw_hh, gb
+
+
 class LstmLayerFn(torch.autograd.Function):
     """Time-major packed (Bi)LSTM layer with fused down-sampling; reference asr.py:476-501.
     x [T,B,I], lens int32 [B], w_ih [ND*4H,I], w_hh [ND,4H,H], b_ih/b_hh [ND*4H] -> y [T_out,B,F_out]."""
 
     @staticmethod
     def forward(ctx, x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
-        L_ = _lib.lib()
-        x = x.contiguous()
-        T, B, Iin = x.shape
-        ND, H4, H = w_hh.shape
-        dev = x.device
-        xproj = gemm(x.view(T * B, Iin), w_ih, transB=True)
-        T_out, F_out = lstm_out_shape(T, H, ND, sr, concat)
-        hf = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
-        y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
-        esz = 2 if _prec == 0 else 4
-        hx = torch.empty(ND * T * B * H * esz, dtype=torch.uint8, device=dev)
-        gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
-        cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
-        sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-        check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
-                                  I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
-                                  ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
-        ctx.save_for_backward(x, lens, w_ih, w_hh, hf, gates, cs, status)
-        ctx.cfg = (sr, int(concat), _prec)
+        y, ctx.saved = _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        L_ = _lib.lib()
-        x, lens, w_ih, w_hh, hf, gates, cs, status = ctx.saved_tensors
-        sr, concat, prec = ctx.cfg
-        T, B, Iin = x.shape
-        ND, H4, H = w_hh.shape
-        dev = x.device
-        gy = gy.contiguous()
-        esz = 2 if prec == 0 else 4
-        dgx = torch.empty(ND * T * B * H4 * esz, dtype=torch.uint8, device=dev)
-        dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
-        sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-        check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
-                                  I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
-              'las_lstm_rec_bwd')
-        x2 = x.view(T * B, Iin)
-        gx = gemm(dgf, w_ih).view(T, B, Iin) if ctx.needs_input_grad[0] else None
-        gw_ih = gemm(dgf, x2, transA=True)                                         # [ND*4H, I]
-        gb = colsum(dgf, torch.empty(ND * H4, dtype=torch.float32, device=dev))
-        gw_hh = torch.empty_like(w_hh)
-        hf2 = hf.view(T * B, ND * H)
-        for d in range(ND):
-            if T > 1:
-                if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
-                    A, Bm = dgf[B:, d * H4:(d + 1) * H4], hf2[:(T - 1) * B, d * H:(d + 1) * H]
-                else:           # sum_{t<=T-2} dg[t]^T h[t+1]
-                    A, Bm = dgf[:(T - 1) * B, d * H4:(d + 1) * H4], hf2[B:, d * H:(d + 1) * H]
-                gemm(A, Bm, gw_hh[d], transA=True)
-            else:
-                gw_hh[d].zero_()
+        gx, gw_ih, gw_hh, gb = _lstm_bwd(ctx.saved, gy, ctx.needs_input_grad[0])
+        ctx.saved = None
         return gx, None, gw_ih, gw_hh, gb, gb.clone(), None, None, None
 
 
 def lstm_layer(x_tm, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
     return LstmLayerFn.apply(x_tm, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status)
+
+
+class _LstmLeavesFn(torch.autograd.Function):
+    """Same op over kernel-facing concatenated views (plain tensors), routing the gradients to the
+    per-direction leaf parameters (reference names weight_ih_l0 / weight_ih_l0_reverse, ...).
+    leaves order: for kind in (w_ih, w_hh, b_ih, b_hh): for direction."""
+
+    @staticmethod
+    def forward(ctx, x, lens, sr, concat, status, cats, *leaves):
+        w_ih, w_hh, b_ih, b_hh = cats
+        y, ctx.saved = _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status)
+        ctx.shapes = [tuple(l.shape) for l in leaves]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx, gw_ih, gw_hh, gb = _lstm_bwd(ctx.saved, gy, ctx.needs_input_grad[0])
+        ND = ctx.saved[3].shape[0]
+        ctx.saved = None
+        out = []
+        k = 0
+        for g in (gw_ih, gw_hh, gb, gb):
+            flat = g.reshape(ND, -1)
+            for d in range(ND):
+                out.append(flat[d].view(ctx.shapes[k]))
+                k += 1
+        return (gx, None, None, None, None, None, *out)
+
+
+def lstm_layer_leaves(x, lens, cats, sr, concat, status, ND, leaves):
+    return _LstmLeavesFn.apply(x, lens, sr, concat, status, cats, *leaves)
+
+
+# ----------------------------------------------------------------------------- joint loss
+class JointLossFn(torch.autograd.Function):
+    """asr_loss = (1-w)*att_loss + w*ctc_loss, reference solver.py:144-164.
+    forward(att_pred [B,L,V]|None, ctc_pred [B,T',V]|None, y i64 [B,Ly], ntok i32 [B], enc_len i32 [B], L, w)
+      -> (asr_loss, att_loss, ctc_loss) 0-dim tensors (att/ctc are non-differentiable by-products)."""
+
+    @staticmethod
+    def forward(ctx, att_pred, ctc_pred, y, ntok, enc_len, L, w):
+        L_ = _lib.lib()
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        att = ctc = datt = None
+        ctx.ctc = None
+        if att_pred is not None:
+            att_pred = att_pred.contiguous()
+            B, Lx, V = att_pred.shape
+            att = torch.empty(1, **f32)
+            datt = torch.empty_like(att_pred)
+            rowloss = torch.empty(B * Lx, **f32)
+            check(L_.las_ce_loss(ptr(att_pred), ptr(y), I(y.shape[1]), ptr(ntok), I(B), I(Lx), I(V), F(1.0 - w),
+                                 ptr(rowloss), ptr(att), ptr(datt), cur_stream()), 'las_ce_loss')
+        if ctc_pred is not None:
+            label = y[:, 1:L + 1].contiguous()
+            nll, la, ctc_ctx = _ctc_fwd(ctc_pred.contiguous(), label, enc_len, ntok, 0)
+            ctc = torch.empty(1, **f32)
+            check(L_.las_norm_mean_fwd(ptr(nll), ptr(ntok), I(nll.shape[0]), ptr(ctc), cur_stream()), 'las_norm_mean_fwd')
+            ctx.ctc = ctc_ctx
+            ctx.log_alpha = la
+        total = torch.empty(1, **f32)
+        check(L_.las_combine2(ptr(att), F(1.0 - w), ptr(ctc), F(w), ptr(total), cur_stream()), 'las_combine2')
+        ctx.datt, ctx.ntok, ctx.w = datt, ntok, w
+        z = torch.zeros((), **f32)
+        outs = (total.view(()), att.view(()) if att is not None else z, ctc.view(()) if ctc is not None else z)
+        ctx.mark_non_differentiable(outs[1], outs[2])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g, _ga, _gc):
+        L_ = _lib.lib()
+        g = g.contiguous().view(1).float()
+        gatt = gctc = None
+        if ctx.datt is not None:
+            gatt = ctx.datt
+            check(L_.las_scale_dev(ptr(gatt), LL(gatt.numel()), ptr(g), cur_stream()), 'las_scale_dev')
+        if ctx.ctc is not None:
+            B = ctx.ntok.shape[0]
+            gs = torch.empty(B, dtype=torch.float32, device=g.device)
+            check(L_.las_norm_mean_bwd(ptr(g), F(ctx.w), ptr(ctx.ntok), I(B), ptr(gs), cur_stream()), 'las_norm_mean_bwd')
+            gctc = _ctc_bwd(ctx.ctc, gs)
+        ctx.datt = ctx.ctc = None
+        return gatt, gctc, None, None, None, None, None
+
+
+def joint_loss(att_pred, ctc_pred, y, ntok, enc_len, L, w):
+    return JointLossFn.apply(att_pred, ctc_pred, y, ntok, enc_len, L, float(w))

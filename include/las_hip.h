@@ -62,13 +62,14 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  *   xproj [T][B][ND*4H] (no bias), b_ih/b_hh [ND*4H], w_hh [ND][4H][H], lens [B] (desc. order not required)
  *   y     [T_out][B][F_out] layer output in next-layer layout (see las_lstm_out_shape); zero at t>=len
  *   hf    [T][B][ND*H] hidden history (fp32); may alias y when sr==1
- *   hx    [ND][T][B][H] exchange copy in the MFMA operand type (bf16: 2 B/elem, f32: 4 B/elem)
+ *   hx    [ND][T][B][Hx] exchange copy in the MFMA operand type (bf16: 2 B/elem, Hx = H rounded up to 8;
+ *         f32: 4 B/elem, Hx = H rounded up to 4); when Hx != H the caller zero-fills it once
  *   gates [T][B][ND*4H] post-activation gates, cs [T][B][ND*H] cell states (saved for bwd)
  *   sync  las_lstm_sync_bytes() bytes of scratch; status: int32, caller-zeroed, set to LAS_E_TIMEOUT if
  *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).
  * bwd: dy [T_out][B][F_out] -> dgf [T][B][ND*4H] (= d loss / d xproj, fp32) and dgx [ND][T][B][4H]
  * (exchange copy, operand type).  dW_ih, dW_hh, db, dx follow from dgf through las_gemm / las_colsum.
- * Limits: H % 8 == 0, B <= 128, ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
+ * Limits: H % 2 == 0, B <= 128, ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
 void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
 size_t las_lstm_sync_bytes(void);
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
@@ -87,6 +88,105 @@ int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* s
 int las_infer_lengths(const float* x, int B, int T, int D, int32_t* lens, void* stream);
 /* out[b] = #nonzero entries of y[b,:] (src/solver.py:136,159) */
 int las_count_nonzero_i64(const int64_t* y, int B, int L, int32_t* out, void* stream);
+
+/* ---- per-step skinny products (M = batch <= 128) --------------------------------------------------
+ * nn.LSTMCell (src/asr.py:329-331, called :353-355): gates = x W_ih^T + b_ih + h W_hh^T + b_hh, then
+ * c' = f*c + i*g, h' = o*tanh(c').  gates_out [B][4C] receives the post-activation gates (i,f,g,o). */
+int las_lstm_cell_fwd(int prec, const float* x, int64_t ldx, int Kx, const float* h_prev, const float* c_prev,
+                      const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int B, int C,
+                      float* h_out, float* c_out, float* gates_out, void* stream);
+/* out[b][n] (+)= act(sum_k x[b][k] w[n][k] + bias[n]); act: 0 none, 1 tanh.  (phi at src/asr.py:383,422;
+ * per-step char_trans :92; backward products with transposed weight copies.) */
+int las_skinny_linear(int prec, const float* x, int64_t ldx, const float* w, int64_t ldw, int B, int N, int K,
+                      const float* bias, int act, int accumulate, float* out, int64_t ldo, void* stream);
+
+/* ---- attend-and-spell decoder loop ------------------------------------------------------------------
+ * One call runs all L decode steps of Seq2Seq.forward (src/asr.py:77-107): Attention.forward (:410-457,
+ * 'dot' / 'loc'), the Speller's LSTMCell stack (:352-357), embedding look-ups and the teacher / sampled /
+ * greedy feedback (:95-102).  All pointers below are device pointers; the structs themselves are host. */
+typedef struct {
+    int B, Tp, E, A, C, NL, V, L;   /* batch, encoder frames, enc dim, att dim, dec dim, dec layers, vocab, steps */
+    int loc;                        /* 0: dot attention, 1: location-aware */
+    int prec;
+} las_dec_dims;
+typedef struct {
+    const float* emb;               /* embed.weight [V][C] */
+    const float* w_phi;             /* attention.phi.weight [A][C] */
+    const float* conv_w;            /* attention.loc_conv.weight [10][1][201]   (loc) */
+    const float* w_lp;              /* attention.loc_proj.weight [A][10]        (loc) */
+    const float* w_e;               /* attention.gen_energy.weight [1][A]       (loc) */
+    const float* b_e;               /* attention.gen_energy.bias [1]            (loc) */
+    const float* w_ih[4];           /* decoder.layer{l}.weight_ih [4C][C+E | C] */
+    const float* w_hh[4];           /* decoder.layer{l}.weight_hh [4C][C] */
+    const float* b_ih[4];
+    const float* b_hh[4];
+    const float* w_char;            /* char_trans.weight [V][C] (only read for sampled / greedy steps) */
+    const float* b_char;
+    /* transposed copies for the backward products (k-contiguous rows), refreshed by the caller */
+    const float* w_ihT[4];          /* [C+E | C][4C] */
+    const float* w_hhT[4];          /* [C][4C] */
+    const float* w_phiT;            /* [C][A] */
+} las_dec_params;
+typedef struct {                    /* saved activations, written by fwd, read by bwd (caller-owned) */
+    int32_t* tok;                   /* [L][B] token fed at each step */
+    float* xin;                     /* [L][B][C+E] cell-0 input (embedding | context) */
+    float* q;                       /* [L][B][A] tanh(phi h0_{t-1}) */
+    float* att;                     /* [L+1][B][Tp] slot t+1 = attention of step t; slot 0 = initial prev_att */
+    float* hs;                      /* [NL][L+1][B][C] slot t+1 = h_t; slot 0 = 0 */
+    float* cs;                      /* [NL][L+1][B][C] */
+    float* gates;                   /* [NL][L][B][4C] post-activation */
+    float* f;                       /* loc: [L][B][10][Tp] location features */
+    float* s;                       /* loc: [L][B][Tp][A] tanh(psi + q + u) */
+    float* ebuf;                    /* [B][Tp] scratch */
+    float* logits_step;             /* [B][V] scratch (sampled / greedy steps) */
+} las_dec_state;
+/* step_mode[t] (host): how the token fed at step t is chosen: 1 teacher y[:,t], 0 sampled from softmax of
+ * step t-1's logits, 2 argmax of step t-1's logits.  step_mode==NULL means all teacher.  y [B][Ly] int64. */
+int las_decoder_fwd(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,
+                    const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode, unsigned seed,
+                    las_dec_state* state, void* stream);
+
+typedef struct {                    /* backward buffers (caller-owned); the driver zeroes what it accumulates into */
+    float* dgates;                  /* [NL][L][B][4C]  d loss / d gate pre-activations */
+    float* dxin;                    /* [L][B][C+E]     d loss / d cell-0 input (embedding | context) */
+    float* dq_pre;                  /* [L][B][A]       d loss / d (phi h) before the tanh */
+    float* de;                      /* dot: [L][B][Tp] d loss / d energy */
+    float* dh_carry;                /* [NL][B][C] */
+    float* dc_carry;                /* [NL][B][C] */
+    float* d_below;                 /* [B][C] scratch */
+    float* da;                      /* [B][Tp] scratch */
+    float* extra;                   /* loc: [2][B][Tp] d loss / d prev_att carried between steps */
+    float* dpsi;                    /* loc: [B][Tp][A] accumulated d loss / d psi(enc) */
+    float* acc;                     /* loc: [B*las_decoder_att_chunks(Tp)][las_decoder_loc_acc_floats(A)] partial sums:
+                                       d w_lp [A*10] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
+    float* demb;                    /* [V][C] d loss / d embed.weight */
+} las_dec_bwd_state;
+int64_t las_decoder_loc_acc_floats(int A);
+int las_decoder_att_chunks(int Tp);
+/* g_htop [L][B][C]: gradient wrt the top-layer hidden state of every step (from char_trans).  After this call
+ * the remaining sums over steps are plain contractions for las_gemm / las_colsum:
+ *   dW_ih[l] = dgates[l]^T x_l, dW_hh[l] = dgates[l]^T hs[l][0:L], db = colsum(dgates[l]), dW_phi = dq_pre^T hs[0][0:L],
+ *   d enc[b] = att[1:,b]^T dxin[:,b,C:],  dot: d psi[b] = de[:,b]^T q[:,b]. */
+int las_decoder_bwd(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,
+                    const int32_t* enc_len, const las_dec_state* state, const float* g_htop,
+                    las_dec_bwd_state* bwd, void* stream);
+
+/* out[c][r] = in[r][c] (weight transposes for the backward skinny products) */
+int las_transpose2d(const float* in, float* out, int R, int C, void* stream);
+
+/* ---- joint loss -----------------------------------------------------------------------------------------
+ * Attention CE: CrossEntropyLoss(ignore_index=0,'none') on att_pred [B][L][V] against label = y[:,1:L+1],
+ * sum_t / ntok_b (ntok_b = #(y[b]!=0)), batch mean (src/solver.py:90,149-155).  One pass also writes
+ * dlogits = gscale * d loss / d logits (pass NULL to skip).  rowloss [B*L] scratch, loss [1]. */
+int las_ce_loss(const float* logits, const int64_t* y, int Ly, const int32_t* ntok, int B, int L, int V, float gscale,
+                float* rowloss, float* loss, float* dlogits, void* stream);
+/* CTCLoss reduction='mean': out[0] = mean_b x[b]/max(n[b],1) (src/solver.py:93,160) and its gradient
+ * gx[b] = g[0]*scale/(B*max(n[b],1)). */
+int las_norm_mean_fwd(const float* x, const int32_t* n, int B, float* out, void* stream);
+int las_norm_mean_bwd(const float* g, float scale, const int32_t* n, int B, float* gx, void* stream);
+/* x *= alpha[0] (device scalar);  out[0] = wa*a[0] + wb*b[0]  ((1-w)*att + w*ctc, src/solver.py:163) */
+int las_scale_dev(float* x, int64_t n, const float* alpha, void* stream);
+int las_combine2(const float* a, float wa, const float* b, float wb, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,81 @@
+"""GPU parity: attend-and-spell decoder loop (HIP, through the C ABI) vs the CPU oracle's step functions.
+f32 mode: atol 3e-5 (attention uses a one-v_exp tanh, abs err ~1e-7 per call); bf16 mode: atol 3e-2."""
+import importlib
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def mods():
+    importlib.import_module('end-to-end-asr-pytorch_amd')
+    return (importlib.import_module('end-to-end-asr-pytorch_amd.ops'),
+            importlib.import_module('end-to-end-asr-pytorch_amd.decoder'))
+
+
+def rand_weights(rng, V, C, E, A, NL, loc):
+    W = {'embed.weight': rng.randn(V, C), 'attention.phi.weight': rng.randn(A, C) / np.sqrt(C),
+         'attention.psi.weight': rng.randn(A, E) / np.sqrt(E), 'attention.psi.bias': 0.1 * rng.randn(A),
+         'char_trans.weight': rng.randn(V, C) / np.sqrt(C), 'char_trans.bias': 0.1 * rng.randn(V)}
+    if loc:
+        W['attention.loc_conv.weight'] = rng.randn(10, 1, 201) / np.sqrt(201)
+        W['attention.loc_proj.weight'] = rng.randn(A, 10) / np.sqrt(10)
+        W['attention.gen_energy.weight'] = rng.randn(1, A) / np.sqrt(A)
+        W['attention.gen_energy.bias'] = 0.1 * rng.randn(1)
+    for l in range(NL):
+        K = C + E if l == 0 else C
+        W[f'decoder.layer{l}.weight_ih'] = rng.randn(4 * C, K) / np.sqrt(K)
+        W[f'decoder.layer{l}.weight_hh'] = rng.randn(4 * C, C) / np.sqrt(C)
+        W[f'decoder.layer{l}.bias_ih'] = 0.1 * rng.randn(4 * C)
+        W[f'decoder.layer{l}.bias_hh'] = 0.1 * rng.randn(4 * C)
+    return {k: v.astype(np.float32) for k, v in W.items()}
+
+
+def oracle_decode(W, enc, lens, y, L, NL, mode):
+    from oracle import las_ref as R
+    Wt = {k: torch.tensor(v) for k, v in W.items()}
+    enc = torch.tensor(enc)
+    B = enc.shape[0]
+    C = W['embed.weight'].shape[1]
+    hs = [torch.zeros(B, C) for _ in range(NL)]
+    cs = [torch.zeros(B, C) for _ in range(NL)]
+    st = R.attention_init(enc, lens, Wt)
+    atts, tops, ctxs = [], [], []
+    for t in range(L):
+        a, ctx = R.attention_step(hs[0], enc, st, Wt, mode)
+        top = R.speller_step(torch.cat([Wt['embed.weight'][torch.tensor(y[:, t])], ctx], -1), hs, cs, Wt, NL)
+        atts.append(a); tops.append(top); ctxs.append(ctx)
+    return torch.stack(atts).numpy(), torch.stack(tops).numpy(), torch.stack(ctxs).numpy(), st['psi'].numpy()
+
+
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode,B,Tp,E,A,C,NL,V,L', [('dot', 3, 9, 10, 7, 6, 1, 9, 4), ('loc', 3, 9, 10, 7, 6, 2, 9, 4),
+                                                    ('loc', 5, 150, 48, 40, 32, 1, 31, 6), ('dot', 20, 75, 64, 32, 64, 1, 63, 5),
+                                                    ('loc', 24, 300, 640, 300, 320, 1, 31, 3)])
+def test_decoder_forward(mods, prec, mode, B, Tp, E, A, C, NL, V, L):
+    ops, dec = mods
+    rng = np.random.RandomState(B * 100 + Tp)
+    W = rand_weights(rng, V, C, E, A, NL, mode == 'loc')
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    att_r, top_r, ctx_r, psi_r = oracle_decode(W, enc, lens, y, L, NL, mode)
+    Wg = {k: torch.tensor(v, device=DEV) for k, v in W.items()}
+    ops.set_precision(prec)
+    try:
+        S = dec.decoder_forward_raw(Wg, torch.tensor(enc, device=DEV), torch.tensor(psi_r, device=DEV),
+                                    torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor(y, device=DEV), L, NL,
+                                    mode == 'loc')
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    tol = dict(atol=3e-5, rtol=1e-4) if prec == 'f32' else dict(atol=3e-2, rtol=3e-2)
+    np.testing.assert_allclose(S['att'][1:].cpu().numpy(), att_r, **tol)
+    np.testing.assert_allclose(S['xin'][:, :, C:].cpu().numpy(), ctx_r, **tol)
+    np.testing.assert_allclose(S['hs'][NL - 1, 1:].cpu().numpy(), top_r, **tol)
+    assert np.array_equal(S['tok'].cpu().numpy(), y[:, :L].T)

@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: real mel-frames/s of the full LAS train step (H2D-free: batches pre-staged in HBM ->
+forward -> joint loss -> backward -> gradient all-reduce -> clip -> optimiser) on synthetic 80-dim fbank batches.
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workloads: c2 (default; BASELINE.json configs[1]: LibriSpeech-100h char-level LAS, attention-only,
+bf16), c3 (= c2 + joint_ctc 0.5), c4 (V=5000, L_max=60), c1 (timit_example.yaml shapes, fp32 MFMA).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline`
+(the CPU oracle timed on this host on a bounded sample of the same workload)."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    'c1': dict(D=39, V=63, B=8, T_max=300, L_max=40, prec='f32', opt=('Adam', 1e-4), ctc=0.0, enc=('256_256_256', '2_2_1'),
+               att=('dot', 256), dec=256, name='TIMIT phoneme LAS (timit_example.yaml shapes), attention-only, fp32'),
+    'c2': dict(D=80, V=31, B=24, T_max=1200, L_max=200, prec='bf16', opt=('Adadelta', 1.0), ctc=0.0,
+               enc=('320_320_320_320_320', '2_2_1_1_1'), att=('loc', 300), dec=320,
+               name='LibriSpeech-100h char-level LAS, attention-only, bf16, 5x320 pBLSTM (2_2_1_1_1 concat), loc-attn'),
+    'c3': dict(D=80, V=31, B=24, T_max=1200, L_max=200, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+               enc=('320_320_320_320_320', '2_2_1_1_1'), att=('loc', 300), dec=320,
+               name='LibriSpeech-100h hybrid CTC+attention (ctc_weight=0.5), bf16'),
+    'c4': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+               enc=('320_320_320_320_320', '2_2_1_1_1'), att=('loc', 300), dec=320,
+               name='LibriSpeech-360h subword (V=5000) LAS+CTC, bf16'),
+}
+
+
+def model_cfg(w):
+    nl = len(w['enc'][0].split('_'))
+    return dict(optimizer=dict(type=w['opt'][0], learning_rate=w['opt'][1], joint_ctc=w['ctc']),
+                encoder=dict(enc_type='BiRNN', sample_rate=w['enc'][1], sample_style='concat', dim=w['enc'][0],
+                             dropout='_'.join(['0'] * nl), rnn_cell='LSTM'),
+                attention=dict(att_mode=w['att'][0], dim=w['att'][1], proj=True, num_head=1),
+                decoder=dict(dim=w['dec'], layer=1, dropout=0, rnn_cell='LSTMCell'))
+
+
+def cpu_baseline(w, cfg, sample_B, steps=1):
+    """The oracle (torch-CPU restatement of the reference step, packed-LSTM fast path) on a bounded sample."""
+    from oracle import las_ref as R
+    synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
+    tr = synth.total_downsample(w['enc'][1])
+    x, y, lens = synth.make_batch(0, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr)
+    x, y, lens = x[:sample_B], y[:sample_B], lens[:sample_B]
+    torch.manual_seed(0)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))           # the 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(cores)
+    # random-init weights of the architecture (reference init scheme), on the CPU
+    asr = importlib.import_module('end-to-end-asr-pytorch_amd.asr')
+    shapes = asr.param_shapes(x, w['V'], cfg)
+    W = {k: (torch.randn(s) / max(1.0, (s[1] if len(s) > 1 else 1) ** 0.5)).numpy() if len(s) > 1 else torch.zeros(s).numpy()
+         for k, s in shapes.items()}
+    ref = R.RefTrainStep(W, cfg, fast=True)
+    t0 = time.time()
+    for _ in range(steps):
+        ref.step(x.numpy(), y.numpy())
+    dt = time.time() - t0
+    frames = sum(lens) * steps
+    return dict(value=frames / dt, unit='mel-frames/s', cores=cores, kind='port',
+                sample=f'{steps} full train step(s) of the oracle on the first {sample_B} utterances of the step-0 '
+                       f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
+
+
+def note(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-b', type=int, default=2)
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload]
+    cfg = model_cfg(w)
+
+    ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+    solver = importlib.import_module('end-to-end-asr-pytorch_amd.solver')
+    synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
+    ldist = importlib.import_module('end-to-end-asr-pytorch_amd.dist')
+    world, rank, local = ldist.init()
+    assert world == a.gpus or world == 1, (world, a.gpus)
+    tmp = tempfile.mkdtemp(prefix='las_bench_')
+    tr = synth.total_downsample(w['enc'][1])
+    config = dict(asr_model=cfg, clm=dict(enable=False),
+                  solver=dict(dataset='synthetic', data_path='', n_jobs=0, max_timestep=0, max_label_len=0,
+                              train_set=['train'], batch_size=w['B'], apex=False, total_steps=10 ** 9, tf_start=1.0,
+                              tf_end=1.0, dev_set=['dev'], dev_batch_size=w['B'], dev_step=10 ** 9, test_set=['test'],
+                              decode_beam_size=1,
+                              synthetic=dict(T_max=w['T_max'], D=w['D'], V=w['V'], L_max=w['L_max'], time_reduction=tr,
+                                             n_batches=1)))
+    paras = argparse.Namespace(gpu=True, name='bench', config='bench.yaml', seed=0, ckpdir=os.path.join(tmp, 'ckpt'),
+                               logdir=os.path.join(tmp, 'log'), load=None, verbose=False, njobs=1)
+    torch.manual_seed(0)
+    ops.set_precision(w['prec'])
+    t = solver.Trainer(config, paras)
+    t.load_data()
+    t.set_model()
+    dev = t.device
+    # pre-stage distinct batches in HBM (per-step seed = 1234 + global batch index; each rank its own shard)
+    n_stage = min(8, a.steps + a.warmup)
+    staged = []
+    for i in range(n_stage):
+        x, y, lens = synth.make_batch(i * world + rank, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr)
+        staged.append((x.to(dev), y.to(dev), sum(lens)))
+    t.asr_opt.zero_grad()
+
+    def run(k0, k):
+        frames = 0
+        for i in range(k0, k0 + k):
+            x, y, f = staged[i % n_stage]
+            t.train_step(x, y, 1.0)
+            frames += f
+        return frames
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    note(f'model built ({t.asr_model.n_params} params), {n_stage} batches staged; warmup {a.warmup}')
+    run(0, a.warmup)
+    barrier()
+    note(f'timing {a.steps} steps')
+    t0 = time.perf_counter()
+    frames = run(a.warmup, a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    stat = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stat[0:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        fsum = stat[1:2].clone()
+        torch.distributed.all_reduce(fsum, op=torch.distributed.ReduceOp.SUM)
+        dt, frames = float(tmax), float(fsum)
+    assert int(t.asr_model.status.item()) == 0, 'persistent LSTM hand-off timed out'
+    skipped = bool(t.asr_opt.norm3[2].item())
+
+    note(f'{dt * 1e3 / a.steps:.1f} ms/step; kernel timing pass')
+    # ---- roofline of the dominant kernel: live HIP-event timing of its launches over 3 more steps
+    prof = ops.enable_kernel_timing()
+    run(a.warmup + a.steps, 3)
+    torch.cuda.synchronize()
+    roof = ops.kernel_timing_summary(prof)
+    ops.disable_kernel_timing()
+
+    if rank == 0:
+        out = {
+            'metric': 'mel-frames/sec per train step (LAS+CTC, 80-dim fbank)', 'value': frames / dt, 'unit': 'mel-frames/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt * 1e3 / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if w['prec'] == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': f"{a.workload}: {w['name']}", 'per_gpu_batch': w['B'], 'global_batch': w['B'] * world,
+                       'T_max': w['T_max'], 'L_max': w['L_max'], 'D': w['D'], 'V': w['V'], 'optimizer': w['opt'][0],
+                       'params': int(t.asr_model.n_params), 'parallelism': f'dp{world}', 'nan_skipped_last_step': skipped},
+            'roofline': roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            note('cpu baseline (oracle on host cores)')
+            out['cpu_baseline'] = cpu_baseline(w, cfg, a.cpu_sample_b)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,10 @@ def lib():
         if not os.path.exists(_SO):
             raise LasError(f'{_SO} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); '
                            'there is no fallback path')
+        # torch must be imported first: it loads its bundled HIP runtime (same soname, libamdhip64.so.7); loading
+        # liblas_hip.so first would pull /opt/rocm's copy into the process and the two runtimes do not share devices
+        # or streams.
+        import torch  # noqa: F401
         L = ctypes.CDLL(_SO)
         for name in declared_symbols():
             if not hasattr(L, name):

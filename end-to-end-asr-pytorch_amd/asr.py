@@ -51,6 +51,14 @@ class FlatParams:
         module.n_params = n
 
 
+def param_shapes(example_input, output_dim, model_para):
+    """{reference parameter name: shape} of the architecture a YAML describes (no device needed)."""
+    class _Probe(Seq2Seq):
+        def _finish(self, fp, device):
+            self._specs = dict(fp.specs)
+    return _Probe(example_input, output_dim, model_para, device='cpu')._specs
+
+
 class Seq2Seq(nn.Module):
     """Listen-Attend-Spell with optional CTC head; reference src/asr.py:18-153."""
 
@@ -129,6 +137,9 @@ class Seq2Seq(nn.Module):
         if self.joint_ctc:
             fp.add('ctc_layer.weight', output_dim, self.enc_out_dim)
             fp.add('ctc_layer.bias', output_dim)
+        self._finish(fp, device)
+
+    def _finish(self, fp, device):
         fp.build(self, device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.sample_seed = 0

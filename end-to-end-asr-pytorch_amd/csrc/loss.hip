@@ -80,6 +80,44 @@ __global__ void combine_kernel(const float* a, float wa, const float* b, float w
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (a ? wa * a[0] : 0.f) + (b ? wb * b[0] : 0.f);
 }
 
+
+// pred[row] = argmax_v logits[row][v] (first maximum)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int V, int32_t* __restrict__ pred) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const float* x = logits + (long)blockIdx.x * V;
+    float v = -INFINITY; int idx = 0;
+    for (int i = threadIdx.x; i < V; i += 256) if (x[i] > v) { v = x[i]; idx = i; }
+    bv[threadIdx.x] = v; bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float ov = bv[threadIdx.x + o]; const int oi = bi[threadIdx.x + o];
+            if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pred[blockIdx.x] = bi[0];
+}
+
+// mean over utterances of token accuracy up to the first 0 label (reference postprocess.py:121-133)
+__global__ void token_acc_kernel(const int32_t* __restrict__ pred, const long long* __restrict__ y, int Ly, int B, int L,
+                                 float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        int correct = 0, total = 0;
+        for (int t = 0; t < L; ++t) {
+            const long long l = y[(long)b * Ly + t + 1];
+            if (l == 0) break;
+            correct += (pred[(long)b * L + t] == (int)l);
+            ++total;
+        }
+        acc += (float)correct / (float)max(total, 1);
+    }
+    out[0] = acc / (float)B;
+}
+
 }  // namespace
 
 extern "C" int las_ce_loss(const float* logits, const int64_t* y, int Ly, const int32_t* ntok, int B, int L, int V,
@@ -121,6 +159,20 @@ extern "C" int las_scale_dev(float* x, int64_t n, const float* alpha, void* stre
 extern "C" int las_combine2(const float* a, float wa, const float* b, float wb, float* out, void* stream) {
     LAS_CHECK_ARG(out && (a || b));
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, wa, b, wb, out);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_argmax_rows(const float* logits, int rows, int V, int32_t* pred, void* stream) {
+    LAS_CHECK_ARG(logits && pred && rows > 0 && V > 0);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, V, pred);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" int las_token_acc(const int32_t* pred, const int64_t* y, int Ly, int B, int L, float* out, void* stream) {
+    LAS_CHECK_ARG(pred && y && out && B > 0 && L > 0 && Ly >= L + 1);
+    hipLaunchKernelGGL(token_acc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pred, (const long long*)y, Ly, B, L, out);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

@@ -81,9 +81,11 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
     sm = None
     if step_mode is not None:
         sm = (ctypes.c_uint8 * L)(*[int(v) for v in step_mode])
-    check(L_.las_decoder_fwd(ctypes.byref(dims), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
-                             ptr(y) if y is not None else None, I(y.shape[1] if y is not None else 0), sm,
-                             ctypes.c_uint(seed & 0xffffffff), ctypes.byref(st), cur_stream()), 'las_decoder_fwd')
+    # algorithmic HBM bytes of the attention steps: psi + enc re-read per step
+    with ops._Timed('decoder_fwd (L attend+spell steps)', 4.0 * L * B * Tp * (A + E), 'byte'):
+        check(L_.las_decoder_fwd(ctypes.byref(dims), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                                 ptr(y) if y is not None else None, I(y.shape[1] if y is not None else 0), sm,
+                                 ctypes.c_uint(seed & 0xffffffff), ctypes.byref(st), cur_stream()), 'las_decoder_fwd')
     S['_dims'], S['_keep'] = dims, (params, st)
     return S
 
@@ -164,8 +166,9 @@ class DecoderFn(torch.autograd.Function):
             setattr(bw, k, v.data_ptr())
         st = S['_keep'][1]
         g_htop = g_htop.contiguous()
-        check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
-                                 ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
+        with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (2 * A + E) * (2 if loc else 1), 'byte'):
+            check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                                     ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
         # ---- contractions over the L steps: one GEMM each
         LB = L * B
         XI = C + E

@@ -5,6 +5,70 @@ from . import _lib
 from ._lib import P, I, Z, F, ptr, check, cur_stream
 
 
+# ----------------------------------------------------------------------------- live kernel timing (bench.py)
+_TIMING = None          # list of (name, start_event, end_event, work, unit) while enabled
+PEAK = {'mfma_bf16': 2500.0, 'mfma_f32': 157.3, 'hbm': 8000.0}     # TFLOP/s, TFLOP/s, GB/s (MI355X_MICROARCH.md)
+
+
+def enable_kernel_timing():
+    global _TIMING
+    _TIMING = []
+    return _TIMING
+
+
+def disable_kernel_timing():
+    global _TIMING
+    _TIMING = None
+
+
+class _Timed:
+    """Brackets a C-ABI call with HIP events on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, name, work, unit):
+        self.args = (name, work, unit)
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            self.e1.record()
+            _TIMING.append((self.args[0], self.e0, self.e1, self.args[1], self.args[2]))
+        return False
+
+
+def kernel_timing_summary(records):
+    """Group the timed launches; the dominant group (largest total time) becomes the `roofline` object."""
+    torch.cuda.synchronize()
+    groups = {}
+    for name, e0, e1, work, unit in records:
+        g = groups.setdefault(name, dict(ms=0.0, n=0, work=0.0, unit=unit))
+        g['ms'] += e0.elapsed_time(e1)
+        g['n'] += 1
+        g['work'] += work
+    rows = []
+    for name, g in groups.items():
+        sec = g['ms'] * 1e-3
+        if g['unit'] == 'flop':
+            peak = PEAK['mfma_f32'] if _prec else PEAK['mfma_bf16']
+            ach = g['work'] / sec / 1e12 if sec > 0 else 0.0
+            rows.append(dict(kernel=name, bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
+                             launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms']))
+        else:
+            ach = g['work'] / sec / 1e9 if sec > 0 else 0.0
+            rows.append(dict(kernel=name, bound='hbm', achieved=ach, peak=PEAK['hbm'], unit='GB/s', frac=ach / PEAK['hbm'],
+                             launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms']))
+    rows.sort(key=lambda r: -r['total_ms'])
+    top = dict(rows[0]) if rows else {}
+    top['traffic'] = None
+    top['breakdown'] = rows
+    return top
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -103,9 +167,10 @@ def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=Non
         if batch > 1:
             sC = M * N
     ldc = ldc if ldc is not None else C.stride(-2)
-    check(L_.las_gemm(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha), P(A.data_ptr()), LL(lda),
-                      LL(sA), P(B.data_ptr()), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc), LL(sC),
-                      P(bias.data_ptr()) if bias is not None else None, I(act), I(batch), cur_stream()), 'las_gemm')
+    with _Timed('gemm (MFMA, fused epilogue)', 2.0 * M * N * K * batch, 'flop'):
+        check(L_.las_gemm(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha), P(A.data_ptr()), LL(lda),
+                          LL(sA), P(B.data_ptr()), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc), LL(sC),
+                          P(bias.data_ptr()) if bias is not None else None, I(act), I(batch), cur_stream()), 'las_gemm')
     return C
 
 
@@ -225,9 +290,10 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-    check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
-                              I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
-                              ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
+    with _Timed('lstm_rec_fwd (persistent BiLSTM recurrence)', 2.0 * ND * T * B * H4 * H, 'flop'):
+        check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
+                                  I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
+                                  ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
     return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec)
 
 
@@ -243,9 +309,10 @@ def _lstm_bwd(saved, gy, need_gx):
     dgx = torch.empty(ND * T * B * H4 * esz, dtype=torch.uint8, device=dev)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-    check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
-                              I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
-          'las_lstm_rec_bwd')
+    with _Timed('lstm_rec_bwd (persistent BiLSTM BPTT)', 2.0 * ND * T * B * H4 * H, 'flop'):
+        check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
+                                  I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
+              'las_lstm_rec_bwd')
     x2 = x.view(T * B, Iin)
     gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
     gw_ih = gemm(dgf, x2, transA=True)                                         # [ND*4H, I]
@@ -370,3 +437,24 @@ class JointLossFn(torch.autograd.Function):
 
 def joint_loss(att_pred, ctc_pred, y, ntok, enc_len, L, w):
     return JointLossFn.apply(att_pred, ctc_pred, y, ntok, enc_len, L, float(w))
+
+
+# ----------------------------------------------------------------------------- metrics
+def argmax_rows(logits):
+    """int32 argmax over the last dim of a contiguous fp32 tensor [..., V]."""
+    L_ = _lib.lib()
+    logits = logits.detach().contiguous()
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    pred = torch.empty(logits.shape[:-1], dtype=torch.int32, device=logits.device)
+    check(L_.las_argmax_rows(ptr(logits), I(rows), I(V), ptr(pred), cur_stream()), 'las_argmax_rows')
+    return pred
+
+
+def token_acc(pred, y):
+    """Device-side cal_acc (reference postprocess.py:121-133): pred i32 [B,L], y i64 [B,Ly] -> 0-dim tensor."""
+    L_ = _lib.lib()
+    B, L = pred.shape
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    check(L_.las_token_acc(ptr(pred), ptr(y), I(y.shape[1]), I(B), I(L), ptr(out), cur_stream()), 'las_token_acc')
+    return out.view(())

@@ -1,0 +1,291 @@
+"""Trainer with the reference's API (src/solver.py:23-291): Trainer(config, paras).load_data() / .set_model() /
+.exec(), same YAML keys, same TensorBoard-style scalar names.  The step body runs entirely in liblas_hip.so
+kernels; host<->device traffic per step is one H2D of the batch and ONE small D2H (lengths + ans_len), and the
+logged scalars are read back one step late so logging never stalls the stream.
+
+Differences from the reference, all recorded in DESIGN.md: scalars also go to <logdir>/scalars.jsonl
+(tensorboardX is used when importable); the best model is saved as a state_dict (+config), not a pickled module;
+`--load` resumes from such a checkpoint; `apex: True` selects the built-in fused Adam."""
+import json
+import math
+import os
+import time
+
+import torch
+
+from . import ops, dist as ldist
+from .asr import Seq2Seq
+from .dataset import LoadDataset
+from .optim import FlatOptimizer
+from .postprocess import Mapper, cal_acc, cal_cer
+
+VAL_STEP = 30            # reference solver.py:18-20
+TRAIN_WER_STEP = 250
+GRAD_CLIP = 5
+
+
+class ScalarLog:
+    """SummaryWriter-shaped sink: add_scalars / add_text / add_image."""
+
+    def __init__(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        self.f = open(os.path.join(logdir, 'scalars.jsonl'), 'a')
+        self.tb = None
+        try:
+            from tensorboardX import SummaryWriter
+            self.tb = SummaryWriter(logdir)
+        except Exception:
+            pass
+        self.history = []
+
+    def add_scalars(self, name, d, step):
+        rec = {'step': int(step), 'name': name, 'values': {k: float(v) for k, v in d.items()}}
+        self.history.append(rec)
+        self.f.write(json.dumps(rec) + '\n')
+        self.f.flush()
+        if self.tb:
+            self.tb.add_scalars(name, rec['values'], step)
+
+    def add_text(self, name, txt, step):
+        self.f.write(json.dumps({'step': int(step), 'name': name, 'text': str(txt)}) + '\n')
+        if self.tb:
+            self.tb.add_text(name, txt, step)
+
+    def add_image(self, name, img, step):
+        if self.tb:
+            self.tb.add_image(name, img, step)
+
+
+class Solver:
+    def __init__(self, config, paras):
+        self.config, self.paras = config, paras
+        self.world, self.rank, self.local_rank = ldist.init() if getattr(paras, 'gpu', True) else (1, 0, 0)
+        if not (getattr(paras, 'gpu', True) and torch.cuda.is_available()):
+            raise ops._lib.LasError('this build has no CPU path: a HIP device is required (the reference CPU path is '
+                                    'restated only as the test oracle under oracle/)')
+        self.device = torch.device('cuda', self.local_rank)
+        torch.cuda.set_device(self.device)
+        self.exp_name = paras.name
+        if self.exp_name is None:
+            self.exp_name = '_'.join([paras.config.split('/')[-1].replace('.yaml', ''), 'sd' + str(paras.seed)])
+        os.makedirs(paras.ckpdir, exist_ok=True)
+        self.ckpdir = os.path.join(paras.ckpdir, self.exp_name)
+        os.makedirs(self.ckpdir, exist_ok=True)
+        if str(config['solver'].get('dataset', '')).upper() == 'SYNTHETIC':
+            V = config['solver'].get('synthetic', {}).get('V', 63)
+            m = {'<sos>': 0, '<eos>': 1}
+            m.update({'t%d' % i: i for i in range(2, V)})
+            self.mapper = Mapper(mapping=m)
+            self.mapper.unit = 'word'
+        else:
+            self.mapper = Mapper(config['solver']['data_path'])
+
+    def verbose(self, msg):
+        if self.paras.verbose and self.rank == 0:
+            print('[INFO]', msg)
+
+    def progress(self, msg):
+        if self.paras.verbose and self.rank == 0:
+            print(msg + '                              ', end='\r')
+
+
+class Trainer(Solver):
+    """Handler for the complete training progress; reference src/solver.py:52-291."""
+
+    def __init__(self, config, paras):
+        super().__init__(config, paras)
+        self.logdir = os.path.join(paras.logdir, self.exp_name)
+        self.log = ScalarLog(self.logdir) if self.rank == 0 else None
+        s = config['solver']
+        self.valid_step, self.max_step = s['dev_step'], s['total_steps']
+        self.tf_start, self.tf_end = s['tf_start'], s['tf_end']
+        self.apex = s.get('apex', False)
+        self.best_val_ed = 2.0
+        self.step = 0
+        if config.get('clm', {}).get('enable', False):
+            raise NotImplementedError('CLM adversarial training is out of scope (SURVEY.md §2.1)')
+        self._pending = None
+
+    # ------------------------------------------------------------------------------------------------ data
+    def load_data(self):
+        self.verbose('Loading data from ' + str(self.config['solver'].get('data_path')))
+        kw = dict(self.config['solver'])
+        kw.update(rank=self.rank, world=self.world)
+        self.train_set = LoadDataset('train', text_only=False, use_gpu=self.paras.gpu, **kw)
+        self.dev_set = LoadDataset('dev', text_only=False, use_gpu=self.paras.gpu, **kw)
+        for self.sample_x, _ in self.train_set:          # one example sizes the model (solver.py:79)
+            break
+        if len(self.sample_x.shape) == 4:
+            self.sample_x = self.sample_x[0]
+
+    # ------------------------------------------------------------------------------------------------ model
+    def set_model(self):
+        self.verbose('Init ASR model. Note: validation is done through greedy decoding w/ attention decoder.')
+        mp = self.config['asr_model']
+        self.asr_model = Seq2Seq(self.sample_x, self.mapper.get_dim(), mp, device=self.device)
+        self.ctc_weight = mp['optimizer']['joint_ctc']
+        self.asr_opt = FlatOptimizer(self.asr_model, mp['optimizer']['type'], mp['optimizer']['learning_rate'], eps=1e-8,
+                                     world_size=self.world)
+        if self.paras.load:
+            ck = torch.load(self.paras.load, map_location=self.device, weights_only=True)
+            self.asr_model.load_reference_state(ck['model'])
+            if 'opt' in ck:
+                self.asr_opt.load_state_dict(ck['opt'])
+            self.step = int(ck.get('step', 0))
+            self.best_val_ed = float(ck.get('best_val_ed', 2.0))
+        ldist.broadcast_params(self.asr_model.flat_params)
+
+    # ------------------------------------------------------------------------------------------------ one step
+    def train_step(self, x, y, tf_rate):
+        """The body of the reference's training loop, solver.py:127-182.  x (B,T,D) / y (B,L+2) on the device.
+        Returns device scalars (loss, att, ctc) and the predictions; nothing here waits on the GPU except the
+        single small read-back of lengths."""
+        lens = ops.infer_lengths(x)                               # solver.py:134, on the device
+        ntok = ops.count_nonzero(y)                               # solver.py:136,159
+        host = torch.cat([lens, ntok.max().view(1)]).cpu().tolist()      # the one D2H sync of the step
+        state_len, ans_len = host[:-1], int(host[-1])
+        ctc_pred, enc_len, att_pred, _ = self.asr_model(x, ans_len, tf_rate=tf_rate, teacher=y, state_len=state_len)
+        loss, att_loss, ctc_loss = ops.joint_loss(att_pred, ctc_pred, y, ntok, self.asr_model.last_enc_len_dev, ans_len,
+                                                  self.ctc_weight)
+        loss.backward()                                           # solver.py:177
+        ldist.allreduce_grads(self.asr_model.flat_grads)
+        self.asr_opt.step(zero_grad=True)                         # clip 5, NaN guard, update (solver.py:178-182)
+        return loss, att_loss, ctc_loss, att_pred, ans_len
+
+    def exec(self):
+        self.verbose('Training set total ' + str(len(self.train_set)) + ' batches.')
+        self.asr_opt.zero_grad()
+        while self.step < self.max_step:
+            for x, y in self.train_set:
+                self.progress('Training step - ' + str(self.step))
+                tf_rate = self.tf_start - self.step * (self.tf_start - self.tf_end) / self.max_step
+                assert len(x.shape) == 4, 'Bucketing should cause acoustic feature to have shape 1xBxTxD'
+                assert len(y.shape) == 3, 'Bucketing should cause label have to shape 1xBxT'
+                x = x.squeeze(0).to(device=self.device, dtype=torch.float32, non_blocking=True)
+                y = y.squeeze(0).to(device=self.device, dtype=torch.long, non_blocking=True)
+                loss, att_loss, ctc_loss, att_pred, ans_len = self.train_step(x, y, tf_rate)
+                self._log_train(loss, att_loss, ctc_loss, att_pred, y, ans_len)
+                if self.step % self.valid_step == 0:
+                    self.valid()
+                self.step += 1
+                if self.step > self.max_step:
+                    break
+        self._flush_log()
+
+    # ------------------------------------------------------------------------------------------------ logging
+    def _log_train(self, loss, att_loss, ctc_loss, att_pred, y, ans_len):
+        """Scalars of solver.py:185-190, read back one step late (pinned, non-blocking)."""
+        vals = [loss.detach().view(1), att_loss.view(1), ctc_loss.view(1), self.asr_opt.norm3]
+        if att_pred is not None:
+            pred = ops.argmax_rows(att_pred)
+            vals.append(ops.token_acc(pred, y).view(1))
+        dev = torch.cat([v.float() for v in vals])
+        buf = torch.empty(dev.shape, dtype=torch.float32, pin_memory=True)
+        buf.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cer = None
+        if self.step % TRAIN_WER_STEP == 0 and att_pred is not None and self.rank == 0:
+            label = y[:, 1:ans_len + 1]
+            cer = cal_cer(pred.cpu().numpy(), label.cpu().numpy(), mapper=self.mapper)
+        self._flush_log()
+        self._pending = (self.step, buf, ev, att_pred is not None, cer)
+
+    def _flush_log(self):
+        if self._pending is None:
+            return
+        step, buf, ev, has_att, cer = self._pending
+        self._pending = None
+        ev.synchronize()
+        v = buf.tolist()
+        self.last_scalars = dict(step=step, loss=v[0], att=v[1], ctc=v[2], grad_norm=v[3], skipped=bool(v[5]))
+        if v[5]:
+            self.verbose('Error : grad norm is NaN @ step ' + str(step))
+        if self.log is None:
+            return
+        d = {}
+        if self.ctc_weight < 1:
+            d['train_att'] = v[1]
+        if self.ctc_weight > 0:
+            d['train_ctc'] = v[2]
+        d['train_full'] = v[0]
+        self.log.add_scalars('loss', d, step)
+        if has_att:
+            self.log.add_scalars('acc', {'train': v[6]}, step)
+        if cer is not None:
+            self.log.add_scalars('error rate', {'train': cer}, step)
+
+    def write_log(self, val_name, val_dict):
+        if self.log is None:
+            return
+        if 'att' in val_name:
+            self.log.add_image(val_name, val_dict, self.step)
+        elif 'txt' in val_name or 'hyp' in val_name:
+            self.log.add_text(val_name, val_dict, self.step)
+        else:
+            self.log.add_scalars(val_name, val_dict, self.step)
+
+    # ------------------------------------------------------------------------------------------------ validation
+    def valid(self):
+        """Greedy-decoding validation, reference solver.py:211-291."""
+        val_ctc = val_att = val_acc = val_cer = 0.0
+        val_len = 0
+        all_pred, all_true = [], []
+        with torch.no_grad():
+            for x, y in self.dev_set:
+                if len(x.shape) == 4:
+                    x = x.squeeze(0)
+                if len(y.shape) == 3:
+                    y = y.squeeze(0)
+                x = x.to(device=self.device, dtype=torch.float32)
+                y = y.to(device=self.device, dtype=torch.long)
+                lens = ops.infer_lengths(x)
+                ntok = ops.count_nonzero(y)
+                host = torch.cat([lens, ntok.max().view(1)]).cpu().tolist()
+                state_len, ans_len = host[:-1], int(host[-1])
+                ctc_pred, enc_len, att_pred, att_maps = self.asr_model(x, ans_len + VAL_STEP, state_len=state_len)
+                B = int(x.shape[0])
+                att_cut = att_pred[:, :ans_len].contiguous() if att_pred is not None else None
+                _, a_l, c_l = ops.joint_loss(att_cut, ctc_pred, y, ntok, self.asr_model.last_enc_len_dev, ans_len,
+                                             self.ctc_weight)
+                label = y[:, 1:ans_len + 1].cpu().numpy()
+                if att_pred is not None:
+                    pred = ops.argmax_rows(att_pred).cpu().numpy()
+                    val_att += float(a_l) * B
+                    t1, t2 = cal_cer(pred, label, mapper=self.mapper, get_sentence=True)
+                    all_pred += t1
+                    all_true += t2
+                    val_acc += cal_acc(pred, label) * B
+                    val_cer += cal_cer(pred, label, mapper=self.mapper) * B
+                if ctc_pred is not None:
+                    val_ctc += float(c_l) * B
+                val_len += B
+        val_loss = (1 - self.ctc_weight) * val_att + self.ctc_weight * val_ctc
+        loss_log = {k: v / val_len for k, v in zip(['dev_full', 'dev_ctc', 'dev_att'], [val_loss, val_ctc, val_att]) if v > 0.0}
+        self.write_log('loss', loss_log)
+        if self.ctc_weight < 1:
+            self.write_log('error rate', {'dev': val_cer / val_len})
+            self.write_log('acc', {'dev': val_acc / val_len})
+            if val_cer / val_len < self.best_val_ed and self.rank == 0:
+                self.best_val_ed = val_cer / val_len
+                self.verbose('Best val er       : {:.4f}       @ step {}'.format(self.best_val_ed, self.step))
+                self.save_checkpoint(os.path.join(self.ckpdir, 'asr'))
+                with open(os.path.join(self.ckpdir, 'best_hyp.txt'), 'w') as f:
+                    for t1, t2 in zip(all_pred, all_true):
+                        f.write(t1 + ',' + t2 + '\n')
+
+    def save_checkpoint(self, path):
+        sd = {k: v.detach().clone() for k, v in self.asr_model.named_parameters()}
+        torch.save({'model': sd, 'opt': self.asr_opt.state_dict(), 'step': self.step, 'best_val_ed': self.best_val_ed,
+                    'config': json.dumps(self.config['asr_model'])}, path)
+
+
+class Tester(Solver):
+    def __init__(self, config, paras):
+        raise NotImplementedError('beam-search decoding (Tester, src/solver.py:294-441) is outside the training hot path '
+                                  '(SURVEY.md §8f N3)')
+
+
+class RNNLM_Trainer(Solver):
+    def __init__(self, config, paras):
+        raise NotImplementedError('RNN-LM training (src/solver.py:444-537) is outside the LAS hot path (SURVEY.md §2.1)')

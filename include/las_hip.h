@@ -188,6 +188,25 @@ int las_norm_mean_bwd(const float* g, float scale, const int32_t* n, int B, floa
 int las_scale_dev(float* x, int64_t n, const float* alpha, void* stream);
 int las_combine2(const float* a, float wa, const float* b, float wb, float* out, void* stream);
 
+/* ---- clip + optimiser over one flat fp32 vector ------------------------------------------------------
+ * las_grad_norm: out3 = { ||gscale*g||_2, clip coefficient min(1, max_norm/(norm+1e-6))*gscale, skip flag (1 if the
+ * norm is NaN) } and, unless skipped, step_dev[0] += 1 -- torch.nn.utils.clip_grad_norm_(params, 5) + the
+ * math.isnan guard at src/solver.py:178-181, without the host sync.  gscale = 1/world_size after a sum all-reduce.
+ * las_adam_step / las_adadelta_step: torch.optim.Adam(lr, betas, eps=1e-8) / Adadelta(lr, rho=0.9, eps=1e-8)
+ * (src/solver.py:101-106,182) applied to coef*g; optionally zero g afterwards (opt.zero_grad, solver.py:139). */
+size_t las_grad_norm_workspace_bytes(void);
+int las_grad_norm(const float* g, int64_t n, float gscale, float max_norm, void* workspace, float* out3,
+                  int32_t* step_dev, void* stream);
+int las_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                  const float* norm3, const int32_t* step_dev, int zero_grad, void* stream);
+int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps,
+                      const float* norm3, int zero_grad, void* stream);
+
+/* training-time accuracy on the device: pred = argmax rows of att_pred; token accuracy up to the first 0 label,
+ * mean over utterances (np.argmax + cal_acc at src/postprocess.py:121-133, called every step at solver.py:187) */
+int las_argmax_rows(const float* logits, int rows, int V, int32_t* pred, void* stream);
+int las_token_acc(const int32_t* pred, const int64_t* y, int Ly, int B, int L, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

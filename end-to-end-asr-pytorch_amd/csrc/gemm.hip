@@ -41,7 +41,8 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ p, int cnt, bo
 
 // Stage-in registers for one operand tile (128 rows x 32 k): 4 float4 per thread.
 // KCONT: element (r,k) at src[r*ld + k]; thread -> row = tid/8 + 32*p, k4 = (tid%8)*4.
-// else : element (r,k) at src[k*ld + r]; thread -> k = tid/32 + 8*p, r4 = (tid%32)*4.
+// else : element (r,k) at src[k*ld + r]; thread -> k = 4*(tid/32) + p, r4 = (tid%32)*4: a 4x4 block that is
+//        transposed in registers so the LDS writes are 4 consecutive k per row (8/16-byte stores).
 template <bool KCONT>
 __device__ __forceinline__ void g_load(float4 (&reg)[4], const float* __restrict__ src, long ld, int row0, int k0,
                                        int rows, int K, bool vec) {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void g_load(float4 (&reg)[4], const float* __restrict
             int cnt = (r < rows) ? min(4, K - k) : 0;
             reg[p] = load4(src + (long)r * ld + k, cnt, vec);
         } else {
-            const int k = k0 + (tid >> 5) + 8 * p, r = row0 + (tid & 31) * 4;
+            const int k = k0 + (tid >> 5) * 4 + p, r = row0 + (tid & 31) * 4;     // thread owns a 4(k) x 4(row) block
             int cnt = (k < K) ? min(4, rows - r) : 0;
             reg[p] = load4(src + (long)k * ld + r, cnt, vec);
         }
@@ -67,15 +68,17 @@ __device__ __forceinline__ void s_store(const float4 (&reg)[4], T* __restrict__ 
     for (int p = 0; p < 4; ++p) {
         if (KCONT) {
             const int r = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
-            T* d = tile + r * LDS_LD + k;
-            d[0] = cvt<T>(reg[p].x); d[1] = cvt<T>(reg[p].y); d[2] = cvt<T>(reg[p].z); d[3] = cvt<T>(reg[p].w);
-        } else {
-            const int k = (tid >> 5) + 8 * p, r = (tid & 31) * 4;
-            tile[(r + 0) * LDS_LD + k] = cvt<T>(reg[p].x);
-            tile[(r + 1) * LDS_LD + k] = cvt<T>(reg[p].y);
-            tile[(r + 2) * LDS_LD + k] = cvt<T>(reg[p].z);
-            tile[(r + 3) * LDS_LD + k] = cvt<T>(reg[p].w);
+            typedef T T4 __attribute__((ext_vector_type(4)));
+            *(T4*)(tile + r * LDS_LD + k) = (T4){cvt<T>(reg[p].x), cvt<T>(reg[p].y), cvt<T>(reg[p].z), cvt<T>(reg[p].w)};
         }
+    }
+    if (!KCONT) {
+        const int k = (tid >> 5) * 4, r = (tid & 31) * 4;
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        *(T4*)(tile + (r + 0) * LDS_LD + k) = (T4){cvt<T>(reg[0].x), cvt<T>(reg[1].x), cvt<T>(reg[2].x), cvt<T>(reg[3].x)};
+        *(T4*)(tile + (r + 1) * LDS_LD + k) = (T4){cvt<T>(reg[0].y), cvt<T>(reg[1].y), cvt<T>(reg[2].y), cvt<T>(reg[3].y)};
+        *(T4*)(tile + (r + 2) * LDS_LD + k) = (T4){cvt<T>(reg[0].z), cvt<T>(reg[1].z), cvt<T>(reg[2].z), cvt<T>(reg[3].z)};
+        *(T4*)(tile + (r + 3) * LDS_LD + k) = (T4){cvt<T>(reg[0].w), cvt<T>(reg[1].w), cvt<T>(reg[2].w), cvt<T>(reg[3].w)};
     }
 }
 
@@ -83,13 +86,15 @@ template <int PREC, bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                   long lda, long sA, const float* __restrict__ B, long ldb, long sB,
                                                   float beta, float* __restrict__ C, long ldc, long sC,
-                                                  const float* __restrict__ bias, int act, int vecA, int vecB) {
+                                                  const float* __restrict__ bias, int act, int vecA, int vecB,
+                                                  int ksplit) {
     typedef typename Elem<PREC>::T T;
     constexpr int LD = BK + Elem<PREC>::PAD;
     __shared__ __attribute__((aligned(16))) T As[BM * LD];
     __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
 
-    const int bz = blockIdx.z;
+    // blockIdx.z = batch index, or (ksplit > 1, batch == 1) the K-slice whose partial product is added atomically
+    const int bz = ksplit > 1 ? 0 : (int)blockIdx.z;
     A += (long)bz * sA; B += (long)bz * sB; C += (long)bz * sC;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -103,10 +108,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 ra[4], rb[4];
-    g_load<A_KCONT>(ra, A, lda, m0, 0, M, K, vecA);
-    g_load<B_KCONT>(rb, B, ldb, n0, 0, N, K, vecB);
-    const int nk = (K + BK - 1) / BK;
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_all = (K + BK - 1) / BK;
+    const int per = (nk_all + ksplit - 1) / ksplit;
+    const int kt0 = ksplit > 1 ? (int)blockIdx.z * per : 0;
+    const int nk = min(nk_all, kt0 + per);
+    if (kt0 >= nk) return;
+    g_load<A_KCONT>(ra, A, lda, m0, kt0 * BK, M, K, vecA);
+    g_load<B_KCONT>(rb, B, ldb, n0, kt0 * BK, N, K, vecB);
+    for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();                       // previous tile's fragment reads are done
         s_store<A_KCONT, T, LD>(ra, As);
         s_store<B_KCONT, T, LD>(rb, Bs);
@@ -159,6 +168,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
                 const int m = m0 + wm + i * 16 + fq * 4 + r;
                 if (m >= M) continue;
                 float* c = C + (long)m * ldc + n;
+                if (ksplit > 1) {                       // C was pre-scaled by beta; bias/act are not allowed here
+                    atomicAdd(c, alpha * acc[i][j][r]);
+                    continue;
+                }
                 float v = alpha * acc[i][j][r] + bv;
                 if (beta != 0.f) v += beta * (*c);
                 if (act == LAS_ACT_TANH) v = tanhf(v);
@@ -171,10 +184,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 template <int PREC>
 int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda,
            long sA, const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
-           int act, int vecA, int vecB) {
+           int act, int vecA, int vecB, int ksplit) {
 #define LAS_GEMM_GO(AK, BK_)                                                                                     \
     hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
-                       sB, beta, C, ldc, sC, bias, act, vecA, vecB)
+                       sB, beta, C, ldc, sC, bias, act, vecA, vecB, ksplit)
     if (!ta && tb) LAS_GEMM_GO(true, true);
     else if (!ta && !tb) LAS_GEMM_GO(true, false);
     else if (ta && !tb) LAS_GEMM_GO(false, false);
@@ -184,20 +197,35 @@ int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float
     return LAS_OK;
 }
 
-// out[n] = beta*out[n] + sum_m X[m,n]   (bias gradients).  One block per 64 columns, 4 row groups.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, float beta,
+// out[n] = beta*out[n] + sum_m X[m,n]   (bias gradients).  grid (N/64, M-slices); slices meet through float atomics
+// after a tiny pre-pass has applied beta.
+// C[m][:] = beta * C[m][:]  (or 0)
+__global__ __launch_bounds__(256) void scale2d_kernel(float beta, int N, float* __restrict__ C, long ldc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) { float* p = C + (long)blockIdx.y * ldc + c; *p = beta != 0.f ? beta * (*p) : 0.f; }
+}
+__global__ __launch_bounds__(256) void colsum_scale_kernel(float beta, int N, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) out[c] = beta != 0.f ? beta * out[c] : 0.f;
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, int rows_per,
                                                      float* __restrict__ out) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < N)
-        for (int m = g; m < M; m += 4) s += X[(long)m * ld + c];
-    part[g][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (g == 0 && c < N) {
-        const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        out[c] = (beta != 0.f ? beta * out[c] : 0.f) + t;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < N) {
+        int m = m0 + g;
+        for (; m + 12 < m1; m += 16) {
+            s0 += X[(long)m * ld + c]; s1 += X[(long)(m + 4) * ld + c];
+            s2 += X[(long)(m + 8) * ld + c]; s3 += X[(long)(m + 12) * ld + c];
+        }
+        for (; m < m1; m += 4) s0 += X[(long)m * ld + c];
     }
+    part[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && c < N)
+        atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 }  // namespace
@@ -212,19 +240,43 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     if (M == 0 || N == 0) return LAS_OK;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     if (grid.y > 65535 || grid.z > 65535) return LAS_E_UNSUPPORTED;
+    // split-K for the weight-gradient shapes (few output tiles, K = T*B in the tens of thousands)
+    int ksplit = 1;
+    const long tiles = (long)grid.x * grid.y;
+    if (batch == 1 && !bias && act == LAS_ACT_NONE && tiles < 256 && K >= 2048) {
+        ksplit = (int)((512 + tiles - 1) / tiles);
+        const int nk = (K + BK - 1) / BK;
+        if (ksplit > nk / 8) ksplit = nk / 8;
+        if (ksplit > 64) ksplit = 64;
+        if (ksplit < 1) ksplit = 1;
+    }
     const int vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (((uintptr_t)A & 15) == 0);
     const int vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (ksplit > 1) {
+        grid.z = ksplit;
+        hipLaunchKernelGGL(scale2d_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, beta, N, C, (long)ldc);
+        LAS_LAUNCH_OK();
+    }
     if (prec == LAS_PREC_BF16)
         return launch<LAS_PREC_BF16>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta,
-                                     C, ldc, strideC, bias, act, vecA, vecB);
+                                     C, ldc, strideC, bias, act, vecA, vecB, ksplit);
     return launch<LAS_PREC_F32>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C,
-                                ldc, strideC, bias, act, vecA, vecB);
+                                ldc, strideC, bias, act, vecA, vecB, ksplit);
 }
 
 extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {
     LAS_CHECK_ARG(X && out && M >= 0 && N > 0 && ld >= N);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ld, M, N, beta, out);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, beta, N, out);
+    LAS_LAUNCH_OK();
+    if (M == 0) return LAS_OK;
+    const int nx = (N + 63) / 64;
+    int slices = (2048 + nx - 1) / nx;                       // ~2048 workgroups in total
+    if (slices > (M + 63) / 64) slices = (M + 63) / 64;
+    if (slices < 1) slices = 1;
+    const int rows_per = ((M + slices - 1) / slices + 3) / 4 * 4;
+    hipLaunchKernelGGL(colsum_kernel, dim3(nx, (M + rows_per - 1) / rows_per), dim3(256), 0, st, X, ld, M, N, rows_per, out);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

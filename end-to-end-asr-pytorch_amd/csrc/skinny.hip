@@ -32,32 +32,44 @@ struct SkinnyArgs {
     const float* c_prev; float* h_out; float* c_out; float* gates_out;
 };
 
-// Copy n source floats (converted) to dst; float4 path when both sides allow it.
-template <typename T>
-__device__ __forceinline__ void stage_piece(T* __restrict__ dst, const float* __restrict__ src, int n, int lane) {
-    const bool vec = ((n & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
+// Stage `nrows` rows x n columns (fp32 source, row r at base + rowidx(r)*ldsrc) into tile[r][dcol..dcol+n) with all
+// 256 threads; 8 independent 16-byte loads are in flight per thread before the first LDS write (the serial
+// load->write->load chain of a row-at-a-time copy costs a full memory latency per row).
+template <typename T, typename RowFn>
+__device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dcol, const float* __restrict__ base,
+                                            long ldsrc, int nrows, int n, RowFn rowidx) {
+    constexpr int U = 8;
+    const bool vec = ((n & 3) == 0) && ((ldsrc & 3) == 0) && ((((uintptr_t)base) & 15) == 0);
     if (vec) {
-        for (int i = lane; i < n / 4; i += 64) {
-            const float4 v = ((const float4*)src)[i];
-            dst[i * 4 + 0] = to_ct<T>(v.x); dst[i * 4 + 1] = to_ct<T>(v.y);
-            dst[i * 4 + 2] = to_ct<T>(v.z); dst[i * 4 + 3] = to_ct<T>(v.w);
+        const int nv = n >> 2, total = nrows * nv;
+        for (int i0 = threadIdx.x; i0 < total; i0 += NT * U) {
+            float4 v[U];
+            int row[U], col[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;
+                row[u] = -1;
+                if (i < total) {
+                    const int r = i / nv;
+                    col[u] = (i - r * nv) << 2;
+                    const long sr = rowidx(r);
+                    if (sr >= 0) { row[u] = r; v[u] = *(const float4*)(base + sr * ldsrc + col[u]); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (row[u] >= 0) {
+                    typedef T T4 __attribute__((ext_vector_type(4)));
+                    *(T4*)(tile + row[u] * ld + dcol + col[u]) = (T4){to_ct<T>(v[u].x), to_ct<T>(v[u].y), to_ct<T>(v[u].z), to_ct<T>(v[u].w)};
+                }
         }
     } else {
-        for (int i = lane; i < n; i += 64) dst[i] = to_ct<T>(src[i]);
-    }
-}
-
-// One LDS row of k-chunk [k0, k0+KC) of the concatenated, per-segment-padded k axis.
-template <typename T>
-__device__ __forceinline__ void stage_chunk_row(T* __restrict__ d, const SkinnyArgs& a, const int (&koff)[4], int k0,
-                                                int KC, long row, bool is_w, bool valid, int lane) {
-    for (int i = lane; i < KC; i += 64) d[i] = (T)0;
-    if (!valid) return;
-    for (int s = 0; s < a.ns; ++s) {
-        const int lo = max(k0, koff[s]), hi = min(k0 + KC, koff[s] + a.seg[s].K);
-        if (hi <= lo) continue;
-        const float* src = (is_w ? a.seg[s].w + row * a.seg[s].ldw : a.seg[s].x + row * a.seg[s].ldx) + (lo - koff[s]);
-        stage_piece<T>(d + (lo - k0), src, hi - lo, lane);
+        const int total = nrows * n;
+        for (int i = threadIdx.x; i < total; i += NT) {
+            const int r = i / n, c = i - r * n;
+            const long sr = rowidx(r);
+            if (sr >= 0) tile[r * ld + dcol + c] = to_ct<T>(base[sr * ldsrc + c]);
+        }
     }
 }
 
@@ -88,11 +100,23 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
     for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ck = 0; ck < NCK; ++ck) {
         if (ck > 0) __syncthreads();
-        // stage A (batch rows) and B (weight rows): one wave per row, round robin
-        for (int r = wave; r < NB * 16; r += 4) stage_chunk_row<T>(Al + r * ld, a, koff, ck * KC, KC, r, false, r < a.B, lane);
-        for (int c = wave; c < 16; c += 4) {
-            const int row = wrow(c);
-            stage_chunk_row<T>(Bl + c * ld, a, koff, ck * KC, KC, row, true, row >= 0, lane);
+        // zero both tiles (pad columns, rows beyond B / beyond N), then drop the real pieces in
+        {
+            typedef T T8 __attribute__((ext_vector_type(16 / sizeof(T))));
+            T8 z;
+#pragma unroll
+            for (int i = 0; i < (int)(16 / sizeof(T)); ++i) z[i] = (T)0;
+            const int nvec = (NB * 16 + 16) * ld / (int)(16 / sizeof(T));
+            for (int i = threadIdx.x; i < nvec; i += NT) ((T8*)Al)[i] = z;
+        }
+        __syncthreads();
+        const int k0 = ck * KC;
+        for (int sidx = 0; sidx < a.ns; ++sidx) {
+            const int lo = max(k0, koff[sidx]), hi = min(k0 + KC, koff[sidx] + a.seg[sidx].K);
+            if (hi <= lo) continue;
+            const int so = lo - koff[sidx];
+            stage_block<T>(Al, ld, lo - k0, a.seg[sidx].x + so, a.seg[sidx].ldx, a.B, hi - lo, [](int r) -> long { return r; });
+            stage_block<T>(Bl, ld, lo - k0, a.seg[sidx].w + so, a.seg[sidx].ldw, 16, hi - lo, [&](int c) -> long { return wrow(c); });
         }
         __syncthreads();
         mma_rows<PREC, NB>(acc, Al + wave * q * KSTEP, ld, Bl + wave * q * KSTEP, ld, q);

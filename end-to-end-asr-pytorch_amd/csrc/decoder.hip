@@ -108,19 +108,28 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
         float acc = 0.f;
         const int tt = t - t0;
         if (t < len) {
-            const float* p = a.psi + ((long)b * a.Tp + t) * a.A;
-            float* so = a.s + ((long)b * a.Tp + t) * a.A;
+            const float* __restrict__ p = a.psi + ((long)b * a.Tp + t) * a.A;
+            float* __restrict__ so = a.s + ((long)b * a.Tp + t) * a.A;
             float fc[LOC_C];
 #pragma unroll
             for (int c = 0; c < LOC_C; ++c) fc[c] = f_l[c * a.TC + tt];
-            for (int i = lane; i < a.A; i += 64) {
-                float u = 0.f;
+            for (int i0 = lane; i0 < a.A; i0 += 256) {          // 4 independent psi loads in flight per lane
+                float pv[4];
 #pragma unroll
-                for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
-                u = fast_tanh(u);
-                const float sv = fast_tanh(p[i] + q_l[i] + u);
-                so[i] = sv;
-                acc += we_l[i] * sv;
+                for (int k = 0; k < 4; ++k) pv[k] = (i0 + 64 * k < a.A) ? p[i0 + 64 * k] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + 64 * k;
+                    if (i < a.A) {
+                        float u = 0.f;
+#pragma unroll
+                        for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
+                        u = fast_tanh(u);
+                        const float sv = fast_tanh(pv[k] + q_l[i] + u);
+                        so[i] = sv;
+                        acc += we_l[i] * sv;
+                    }
+                }
             }
             acc = wave_sum(acc) + be;
         }
@@ -154,8 +163,17 @@ __global__ __launch_bounds__(256) void att_softmax_ctx(int Tp, int E, const floa
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), tg = threadIdx.x >> 6;
     float acc = 0.f;
     if (col < E) {
-        const float* p = enc + (long)b * Tp * E + col;
-        for (int t = tg; t < len; t += 4) acc += a_l[t] * p[(long)t * E];
+        const float* __restrict__ p = enc + (long)b * Tp * E + col;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        int t = tg;
+        for (; t + 12 < len; t += 16) {
+            c0 += a_l[t] * p[(long)t * E];
+            c1 += a_l[t + 4] * p[(long)(t + 4) * E];
+            c2 += a_l[t + 8] * p[(long)(t + 8) * E];
+            c3 += a_l[t + 12] * p[(long)(t + 12) * E];
+        }
+        for (; t < len; t += 4) c0 += a_l[t] * p[(long)t * E];
+        acc = (c0 + c1) + (c2 + c3);
     }
     part[tg * 64 + (threadIdx.x & 63)] = acc;
     __syncthreads();
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(256) void pick_token_kernel(const float* __restrict
     (void)red;
 }
 
-int att_chunks(int Tp) { int n = (Tp + 63) / 64; return n < 1 ? 1 : (n > 16 ? 16 : n); }
+int att_chunks(int Tp) { int n = (Tp + 19) / 20; return n < 1 ? 1 : (n > 32 ? 32 : n); }
 
 }  // namespace
 

@@ -53,11 +53,28 @@ __global__ __launch_bounds__(256) void att_bwd_da(int Tp, int E, int TC, const f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < E; i += 256) sm[i] = dctx[(long)b * ld_dctx + i];
     __syncthreads();
+    const bool vec = (E & 3) == 0 && ((((uintptr_t)enc) & 15) == 0);
     for (int t = t0 + wave; t < t1; t += 4) {
         float acc = 0.f;
         if (t < len) {
-            const float* p = enc + ((long)b * Tp + t) * E;
-            for (int i = lane; i < E; i += 64) acc += p[i] * sm[i];
+            const float* __restrict__ p = enc + ((long)b * Tp + t) * E;
+            if (vec) {
+                float a0 = 0.f, a1 = 0.f;
+                int i = lane;
+                for (; i + 64 < E / 4; i += 128) {
+                    const float4 v0 = ((const float4*)p)[i], v1 = ((const float4*)p)[i + 64];
+                    const float4 w0 = ((const float4*)sm)[i], w1 = ((const float4*)sm)[i + 64];
+                    a0 += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w;
+                    a1 += v1.x * w1.x + v1.y * w1.y + v1.z * w1.z + v1.w * w1.w;
+                }
+                for (; i < E / 4; i += 64) {
+                    const float4 v0 = ((const float4*)p)[i], w0 = ((const float4*)sm)[i];
+                    a0 += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w;
+                }
+                acc = a0 + a1;
+            } else {
+                for (int i = lane; i < E; i += 64) acc += p[i] * sm[i];
+            }
             acc = wave_sum(acc);
             if (extra) acc += extra[(long)b * Tp + t];
         }
@@ -109,20 +126,30 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     __syncthreads();
     if (!LOC) {
         // dq[a] = sum_t de[t] * psi[b,t,a]
+        const int tv = min(t1, len);
         for (int i = threadIdx.x; i < a.A; i += 256) {
-            float acc = 0.f;
-            for (int t = t0; t < min(t1, len); ++t) acc += de_l[t - t0] * a.psi[((long)b * a.Tp + t) * a.A + i];
+            float acc0 = 0.f, acc1 = 0.f;
+            const float* __restrict__ p = a.psi + ((long)b * a.Tp) * a.A + i;
+            int t = t0;
+            for (; t + 1 < tv; t += 2) {
+                acc0 += de_l[t - t0] * p[(long)t * a.A];
+                acc1 += de_l[t + 1 - t0] * p[(long)(t + 1) * a.A];
+            }
+            if (t < tv) acc0 += de_l[t - t0] * p[(long)t * a.A];
             const float qv = a.q[(long)b * a.A + i];
-            atomicAdd(&a.dq_pre[(long)b * a.A + i], acc * (1.f - qv * qv));
+            atomicAdd(&a.dq_pre[(long)b * a.A + i], (acc0 + acc1) * (1.f - qv * qv));
         }
         return;
     }
+    const int tcv = min(t1, len) - t0;               // valid frames in this chunk
+    if (tcv <= 0) return;                            // whole chunk beyond the utterance: nothing flows
     float* we_l = de_l + a.TC;                       // [A]
     float* wlp_l = we_l + a.A;                       // [10][A]
     float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
     float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
-    float* df_l = prev_l + a.TC + 2 * LOC_K;         // [10][TC]
-    float* acc_l = df_l + LOC_C * a.TC;              // [4][A*12] cross-wave reduction scratch
+    float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]  saved location features of this chunk
+    float* df_l = f_l + LOC_C * a.TC;                // [10][TC]
+    float* acc_l = df_l + LOC_C * a.TC;              // [A][12] = {dq, dwe, dwlp[10]} summed over the block (LDS atomics)
     for (int i = threadIdx.x; i < a.A; i += 256) we_l[i] = a.w_e[i];
     for (int i = threadIdx.x; i < LOC_C * a.A; i += 256) { const int aa = i / LOC_C, c = i % LOC_C; wlp_l[c * a.A + aa] = a.w_lp[i]; }
     for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) cw_l[i] = a.conv_w[i];
@@ -130,7 +157,12 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         const int t = t0 - LOC_K + i;
         prev_l[i] = (t >= 0 && t < a.Tp) ? a.prev[(long)b * a.Tp + t] : 0.f;
     }
-    for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) df_l[i] = 0.f;
+    for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
+        const int c = i / a.TC, tt = i % a.TC;
+        f_l[i] = (tt < tcv) ? a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] : 0.f;
+        df_l[i] = 0.f;
+    }
+    for (int i = threadIdx.x; i < a.A * 12; i += 256) acc_l[i] = 0.f;
     __syncthreads();
     float dq_r[AI], dwe_r[AI], dwlp_r[AI][LOC_C];
 #pragma unroll
@@ -140,15 +172,22 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
     }
     float dbe = 0.f;
-    for (int t = t0 + wave; t < min(t1, len); t += 4) {
-        const int tt = t - t0;
+    for (int tt = wave; tt < tcv; tt += 4) {
+        const int t = t0 + tt;
         const float de = de_l[tt];
         dbe += de;
         float fc[LOC_C], dfc[LOC_C];
 #pragma unroll
-        for (int c = 0; c < LOC_C; ++c) { fc[c] = a.f[((long)b * LOC_C + c) * a.Tp + t]; dfc[c] = 0.f; }
-        const float* sp = a.s + ((long)b * a.Tp + t) * a.A;
-        float* dp = a.dpsi + ((long)b * a.Tp + t) * a.A;
+        for (int c = 0; c < LOC_C; ++c) { fc[c] = f_l[c * a.TC + tt]; dfc[c] = 0.f; }
+        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
+        float* __restrict__ dp = a.dpsi + ((long)b * a.Tp + t) * a.A;
+        float sv[AI], dpv[AI];                       // all loads of the row first (independent, in flight together)
+#pragma unroll
+        for (int k = 0; k < AI; ++k) {
+            const int i = lane + 64 * k;
+            sv[k] = i < a.A ? sp[i] : 0.f;
+            dpv[k] = i < a.A ? dp[i] : 0.f;
+        }
 #pragma unroll
         for (int k = 0; k < AI; ++k) {
             const int i = lane + 64 * k;
@@ -157,11 +196,10 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
                 u = fast_tanh(u);
-                const float sv = sp[i];
-                const float dz = de * we_l[i] * (1.f - sv * sv);
+                const float dz = de * we_l[i] * (1.f - sv[k] * sv[k]);
                 dq_r[k] += dz;
-                dp[i] += dz;
-                dwe_r[k] += de * sv;
+                dp[i] = dpv[k] + dz;
+                dwe_r[k] += de * sv[k];
                 const float du = dz * (1.f - u * u);
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) { dwlp_r[k][c] += du * fc[c]; dfc[c] += du * wlp_l[c * a.A + i]; }
@@ -173,15 +211,15 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
             if (lane == 0) df_l[c * a.TC + tt] = v;
         }
     }
-    // ---- cross-wave reduction of the per-lane accumulators: acc_l[wave][a][12] = {dq, dwe, dwlp[10]}
+    // ---- block reduction of the per-lane accumulators through LDS float atomics
 #pragma unroll
     for (int k = 0; k < AI; ++k) {
         const int i = lane + 64 * k;
         if (i < a.A) {
-            float* o = acc_l + ((long)wave * a.A + i) * 12;
-            o[0] = dq_r[k]; o[1] = dwe_r[k];
+            float* o = acc_l + i * 12;
+            atomicAdd(&o[0], dq_r[k]); atomicAdd(&o[1], dwe_r[k]);
 #pragma unroll
-            for (int c = 0; c < LOC_C; ++c) o[2 + c] = dwlp_r[k][c];
+            for (int c = 0; c < LOC_C; ++c) atomicAdd(&o[2 + c], dwlp_r[k][c]);
         }
     }
     dbe = wave_sum(dbe);
@@ -190,7 +228,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     float* accg = a.acc + ((long)b * a.NCH + ch) * a.acc_stride;
     for (int i = threadIdx.x; i < a.A * 12; i += 256) {
         const int aa = i / 12, j = i % 12;
-        const float v = acc_l[i] + acc_l[a.A * 12 + i] + acc_l[2 * a.A * 12 + i] + acc_l[3 * a.A * 12 + i];
+        const float v = acc_l[i];
         if (j == 0) {
             const float qv = a.q[(long)b * a.A + aa];
             atomicAdd(&a.dq_pre[(long)b * a.A + aa], v * (1.f - qv * qv));
@@ -203,25 +241,22 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     if (threadIdx.x == 0) accg[a.A * LOC_C + a.A] += red[0] + red[1] + red[2] + red[3];
     // ---- location conv backward
     // d prev[tau] += sum_c sum_{t in chunk} w[c][tau - t + K] * df[c][t]
-    const int tcv = min(t1, len) - t0;               // valid frames in this chunk
-    if (tcv > 0) {
-        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
-            const int tau = t0 - LOC_K + i;
-            if (tau < 0 || tau >= a.Tp) continue;
-            float acc = 0.f;
-            const int lo = max(0, tau - LOC_K - t0), hi = min(tcv, tau + LOC_K - t0 + 1);
-            for (int c = 0; c < LOC_C; ++c)
-                for (int tt = lo; tt < hi; ++tt) acc += cw_l[c * LOC_W + (tau - (t0 + tt) + LOC_K)] * df_l[c * a.TC + tt];
-            if (acc != 0.f) atomicAdd(&a.extra_out[(long)b * a.Tp + tau], acc);
-        }
-        // d w[c][k] += sum_{t in chunk} df[c][t] * prev[t + k - K]
-        const long conv_off = ((a.A * LOC_C + a.A + 1 + 3) / 4) * 4;
-        for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) {
-            const int c = i / LOC_W, k = i % LOC_W;
-            float acc = 0.f;
-            for (int tt = 0; tt < tcv; ++tt) acc += df_l[c * a.TC + tt] * prev_l[tt + k];
-            accg[conv_off + i] += acc;
-        }
+    for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
+        const int tau = t0 - LOC_K + i;
+        if (tau < 0 || tau >= a.Tp) continue;
+        float acc = 0.f;
+        const int lo = max(0, tau - LOC_K - t0), hi = min(tcv, tau + LOC_K - t0 + 1);
+        for (int c = 0; c < LOC_C; ++c)
+            for (int tt = lo; tt < hi; ++tt) acc += cw_l[c * LOC_W + (tau - (t0 + tt) + LOC_K)] * df_l[c * a.TC + tt];
+        if (acc != 0.f) atomicAdd(&a.extra_out[(long)b * a.Tp + tau], acc);
+    }
+    // d w[c][k] += sum_{t in chunk} df[c][t] * prev[t + k - K]
+    const long conv_off = ((a.A * LOC_C + a.A + 1 + 3) / 4) * 4;
+    for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) {
+        const int c = i / LOC_W, k = i % LOC_W;
+        float acc = 0.f;
+        for (int tt = 0; tt < tcv; ++tt) acc += df_l[c * a.TC + tt] * prev_l[tt + k];
+        accg[conv_off + i] += acc;
     }
 }
 
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&demb[(long)tk * C + i], dx[(long)r * ldx + i]);
 }
 
-int att_chunks(int Tp) { int n = (Tp + 63) / 64; return n < 1 ? 1 : (n > 16 ? 16 : n); }
+int att_chunks(int Tp) { int n = (Tp + 19) / 20; return n < 1 ? 1 : (n > 32 ? 32 : n); }
 
 }  // namespace
 
@@ -263,7 +298,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * NCH * acc_stride, st));
     }
     size_t lds_e = sizeof(float) * (size_t)TC;
-    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + LOC_C * TC + 4 * (size_t)A * 12);
+    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC + (size_t)A * 12);
     if (lds_e > 160 * 1024) return LAS_E_UNSUPPORTED;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first

@@ -73,6 +73,50 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
     }
 }
 
+template <int NB>
+__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float* __restrict__ Gl, int blk) {
+    auto wrow = [&](int c) -> int {
+        if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
+        const int n = blk * 16 + c;
+        return n < a.N ? n : -1;
+    };
+    if (a.mode != 2) {
+        for (int e = threadIdx.x; e < a.B * 16; e += NT) {
+            const int b = e >> 4, c = e & 15, row = wrow(c);
+            if (row < 0) continue;
+            float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] + Gl[(2 * NB * 16 + b) * 17 + c] +
+                      Gl[(3 * NB * 16 + b) * 17 + c];
+            if (a.bias0) v += a.bias0[row];
+            if (a.bias1) v += a.bias1[row];
+            float* o = a.out + (long)b * a.ldo + row;
+            if (a.accumulate) v += *o;
+            if (a.mode == 1) v = tanhf(v);
+            *o = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < a.B * 4; e += NT) {
+            const int b = e >> 2, jj = e & 3, u = blk * 4 + jj;
+            if (u >= a.C) continue;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = g * 4 + jj, row = g * a.C + u;
+                float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] +
+                          Gl[(2 * NB * 16 + b) * 17 + c] + Gl[(3 * NB * 16 + b) * 17 + c];
+                if (a.bias0) v += a.bias0[row];
+                if (a.bias1) v += a.bias1[row];
+                pre[g] = v;
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float cn = fg * a.c_prev[(long)b * a.C + u] + ig * gg;
+            a.c_out[(long)b * a.C + u] = cn;
+            a.h_out[(long)b * a.C + u] = og * tanhf(cn);
+            float* go = a.gates_out + (long)b * 4 * a.C;
+            go[u] = ig; go[a.C + u] = fg; go[2 * a.C + u] = gg; go[3 * a.C + u] = og;
+        }
+    }
+}
+
 template <int PREC, int NB>
 __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NCK) {
     typedef typename CT<PREC>::T T;
@@ -127,42 +171,70 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    // ---- epilogue
-    if (a.mode != 2) {
-        for (int e = threadIdx.x; e < a.B * 16; e += NT) {
-            const int b = e >> 4, c = e & 15, row = wrow(c);
-            if (row < 0) continue;
-            float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] + Gl[(2 * NB * 16 + b) * 17 + c] +
-                      Gl[(3 * NB * 16 + b) * 17 + c];
-            if (a.bias0) v += a.bias0[row];
-            if (a.bias1) v += a.bias1[row];
-            float* o = a.out + (long)b * a.ldo + row;
-            if (a.accumulate) v += *o;
-            if (a.mode == 1) v = tanhf(v);
-            *o = v;
-        }
-    } else {
-        for (int e = threadIdx.x; e < a.B * 4; e += NT) {
-            const int b = e >> 2, jj = e & 3, u = blk * 4 + jj;
-            if (u >= a.C) continue;
-            float pre[4];
+    skinny_epilogue<NB>(a, Gl, blk);
+}
+
+// ---- direct variant: both operands go global -> registers -> MFMA, no LDS staging, no barriers before the
+// reduction.  Weights are streamed once and not shared between waves, activations are L2 hits: the LDS round trip
+// is pure overhead at M = batch (cdna_hip_programming.md, "GEMV / M <= 16 decode weights").  Requires every
+// segment to start 16-byte aligned with K_s % 4 == 0 (each lane's two float4 halves are either inside or outside).
+// bf16 only: lane (fr = lane&15, fq = lane>>4) holds k = 32*ks + 8*fq + {0..7} of row fr.
+template <int NB>
+__global__ __launch_bounds__(NT) void skinny_direct_kernel(SkinnyArgs a) {
+    __shared__ float Gl[4 * NB * 16 * 17];
+    const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    auto wrow = [&](int c) -> int {
+        if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
+        const int n = blk * 16 + c;
+        return n < a.N ? n : -1;
+    };
+    const int row = wrow(fr);
+    f32x4 acc[NB];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = g * 4 + jj, row = g * a.C + u;
-                float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] +
-                          Gl[(2 * NB * 16 + b) * 17 + c] + Gl[(3 * NB * 16 + b) * 17 + c];
-                if (a.bias0) v += a.bias0[row];
-                if (a.bias1) v += a.bias1[row];
-                pre[g] = v;
+    for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto pack = [](const float4& lo, const float4& hi) -> bf16x8 {
+        bf16x8 r;
+        r[0] = (short)f2bf(lo.x); r[1] = (short)f2bf(lo.y); r[2] = (short)f2bf(lo.z); r[3] = (short)f2bf(lo.w);
+        r[4] = (short)f2bf(hi.x); r[5] = (short)f2bf(hi.y); r[6] = (short)f2bf(hi.z); r[7] = (short)f2bf(hi.w);
+        return r;
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sidx = 0; sidx < a.ns; ++sidx) {
+        const Seg& sg = a.seg[sidx];
+        const int nks = (sg.K + 31) / 32;
+        const float* __restrict__ wp = row >= 0 ? sg.w + (long)row * sg.ldw : nullptr;
+        // wave w takes k-steps w, w+4, ...; two k-steps are in flight per iteration
+        for (int ks = wave; ks < nks; ks += 8) {
+            float4 bw[2][2], ax[2][NB][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = (ks + 4 * u) * 32 + fq * 8;
+                const bool live = (ks + 4 * u) < nks;
+                bw[u][0] = (live && wp && k < sg.K) ? *(const float4*)(wp + k) : z4;
+                bw[u][1] = (live && wp && k + 4 < sg.K) ? *(const float4*)(wp + k + 4) : z4;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    const int b = bt * 16 + fr;
+                    const float* xp = sg.x + (long)b * sg.ldx + k;
+                    ax[u][bt][0] = (live && b < a.B && k < sg.K) ? *(const float4*)xp : z4;
+                    ax[u][bt][1] = (live && b < a.B && k + 4 < sg.K) ? *(const float4*)(xp + 4) : z4;
+                }
             }
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-            const float cn = fg * a.c_prev[(long)b * a.C + u] + ig * gg;
-            a.c_out[(long)b * a.C + u] = cn;
-            a.h_out[(long)b * a.C + u] = og * tanhf(cn);
-            float* go = a.gates_out + (long)b * 4 * a.C;
-            go[u] = ig; go[a.C + u] = fg; go[2 * a.C + u] = gg; go[3 * a.C + u] = og;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 bf = pack(bw[u][0], bw[u][1]);
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt)
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack(ax[u][bt][0], ax[u][bt][1]), bf, acc[bt], 0, 0, 0);
+            }
         }
     }
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
+    __syncthreads();
+    skinny_epilogue<NB>(a, Gl, blk);
 }
 
 constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU
@@ -208,6 +280,18 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
     const int NB = las_pick_nb(B);
     if (NB == 0 || B <= 0 || N <= 0 || K0 <= 0) return LAS_E_UNSUPPORTED;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
+    if (prec == LAS_PREC_BF16) {
+        bool ok = true;
+        for (int i = 0; i < a.ns; ++i) {
+            const Seg& g = a.seg[i];
+            ok = ok && (g.K % 4 == 0) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) && ((((uintptr_t)g.x) & 15) == 0) &&
+                 ((((uintptr_t)g.w) & 15) == 0);
+        }
+        if (ok) {
+            const int grid_d = mode == 2 ? (C + 3) / 4 : (N + 15) / 16;
+            LAS_NB_SWITCH(NB, { hipLaunchKernelGGL((skinny_direct_kernel<NB_>), dim3(grid_d), dim3(NT), 0, st, a); LAS_LAUNCH_OK(); return LAS_OK; });
+        }
+    }
     int KC = 0, NCK = 0;
     const size_t lds = skinny_plan(prec, a, NB, KC, NCK);
     if (lds > 160 * 1024) return LAS_E_UNSUPPORTED;

@@ -27,14 +27,22 @@ class FlatParams:
     def add(self, name, *shape):
         self.specs.append((name, tuple(shape)))
 
+    ALIGN = 64          # floats: every parameter starts 256-byte aligned (vector loads in the kernels)
+
     def build(self, module, device):
-        n = sum(math.prod(s) for _, s in self.specs)
-        pad = (-n) % 4
-        module.flat_params = torch.zeros(n + pad, dtype=torch.float32, device=device)
-        module.flat_grads = torch.zeros(n + pad, dtype=torch.float32, device=device)
+        """Adjacent per-direction LSTM parameters must stay contiguous (kernel-facing concatenated views), so
+        alignment padding is only inserted where the next spec is not a `_reverse` twin."""
+        offs, off = [], 0
+        for i, (name, shape) in enumerate(self.specs):
+            if not name.endswith('_reverse'):
+                off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            offs.append(off)
+            off += math.prod(shape)
+        total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        module.flat_params = torch.zeros(total, dtype=torch.float32, device=device)
+        module.flat_grads = torch.zeros(total, dtype=torch.float32, device=device)
         module.param_slices = {}
-        off = 0
-        for name, shape in self.specs:
+        for (name, shape), off in zip(self.specs, offs):
             k = math.prod(shape)
             p = nn.Parameter(module.flat_params[off:off + k].view(shape))
             p.grad = module.flat_grads[off:off + k].view(shape)
@@ -47,8 +55,7 @@ class FlatParams:
                     obj.add_module(q, nn.Module())
                 obj = getattr(obj, q)
             obj.register_parameter(parts[-1], p)
-            off += k
-        module.n_params = n
+        module.n_params = sum(math.prod(s) for _, s in self.specs)
 
 
 def param_shapes(example_input, output_dim, model_para):

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     dbe = wave_sum(dbe);
     if (lane == 0) red[wave] = dbe;
     __syncthreads();
-    float* accg = a.acc + ((long)b * a.NCH + ch) * a.acc_stride;
+    float* accg = a.acc + (long)b * a.acc_stride;      // one accumulator row per utterance (float atomics)
     for (int i = threadIdx.x; i < a.A * 12; i += 256) {
         const int aa = i / 12, j = i % 12;
         const float v = acc_l[i];
@@ -233,12 +233,12 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
             const float qv = a.q[(long)b * a.A + aa];
             atomicAdd(&a.dq_pre[(long)b * a.A + aa], v * (1.f - qv * qv));
         } else if (j == 1) {
-            accg[a.A * LOC_C + aa] += v;
+            atomicAdd(&accg[a.A * LOC_C + aa], v);
         } else {
-            accg[aa * LOC_C + (j - 2)] += v;
+            atomicAdd(&accg[aa * LOC_C + (j - 2)], v);
         }
     }
-    if (threadIdx.x == 0) accg[a.A * LOC_C + a.A] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) atomicAdd(&accg[a.A * LOC_C + a.A], red[0] + red[1] + red[2] + red[3]);
     // ---- location conv backward
     // d prev[tau] += sum_c sum_{t in chunk} w[c][tau - t + K] * df[c][t]
     for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         const int c = i / LOC_W, k = i % LOC_W;
         float acc = 0.f;
         for (int tt = 0; tt < tcv; ++tt) acc += df_l[c * a.TC + tt] * prev_l[tt + k];
-        accg[conv_off + i] += acc;
+        atomicAdd(&accg[conv_off + i], acc);
     }
 }
 
@@ -295,7 +295,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
     if (loc) {
         LAS_HIP(hipMemsetAsync(w.extra, 0, sizeof(float) * 2 * (size_t)B * Tp, st));
         LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
-        LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * NCH * acc_stride, st));
+        LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
     }
     size_t lds_e = sizeof(float) * (size_t)TC;
     if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC + (size_t)A * 12);

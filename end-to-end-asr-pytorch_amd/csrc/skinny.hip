@@ -73,19 +73,24 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
     }
 }
 
-template <int NB>
+template <int NB, int NWAVES>
 __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float* __restrict__ Gl, int blk) {
+    auto gsum = [&](int b, int c) -> float {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) v += Gl[(w * NB * 16 + b) * 17 + c];
+        return v;
+    };
     auto wrow = [&](int c) -> int {
         if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
         const int n = blk * 16 + c;
         return n < a.N ? n : -1;
     };
     if (a.mode != 2) {
-        for (int e = threadIdx.x; e < a.B * 16; e += NT) {
+        for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
             const int b = e >> 4, c = e & 15, row = wrow(c);
             if (row < 0) continue;
-            float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] + Gl[(2 * NB * 16 + b) * 17 + c] +
-                      Gl[(3 * NB * 16 + b) * 17 + c];
+            float v = gsum(b, c);
             if (a.bias0) v += a.bias0[row];
             if (a.bias1) v += a.bias1[row];
             float* o = a.out + (long)b * a.ldo + row;
@@ -94,15 +99,14 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
             *o = v;
         }
     } else {
-        for (int e = threadIdx.x; e < a.B * 4; e += NT) {
+        for (int e = threadIdx.x; e < a.B * 4; e += NWAVES * 64) {
             const int b = e >> 2, jj = e & 3, u = blk * 4 + jj;
             if (u >= a.C) continue;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = g * 4 + jj, row = g * a.C + u;
-                float v = Gl[(0 * NB * 16 + b) * 17 + c] + Gl[(1 * NB * 16 + b) * 17 + c] +
-                          Gl[(2 * NB * 16 + b) * 17 + c] + Gl[(3 * NB * 16 + b) * 17 + c];
+                float v = gsum(b, c);
                 if (a.bias0) v += a.bias0[row];
                 if (a.bias1) v += a.bias1[row];
                 pre[g] = v;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    skinny_epilogue<NB>(a, Gl, blk);
+    skinny_epilogue<NB, 4>(a, Gl, blk);
 }
 
 // ---- direct variant: both operands go global -> registers -> MFMA, no LDS staging, no barriers before the
@@ -179,9 +183,10 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
 // is pure overhead at M = batch (cdna_hip_programming.md, "GEMV / M <= 16 decode weights").  Requires every
 // segment to start 16-byte aligned with K_s % 4 == 0 (each lane's two float4 halves are either inside or outside).
 // bf16 only: lane (fr = lane&15, fq = lane>>4) holds k = 32*ks + 8*fq + {0..7} of row fr.
-template <int NB>
-__global__ __launch_bounds__(NT) void skinny_direct_kernel(SkinnyArgs a) {
-    __shared__ float Gl[4 * NB * 16 * 17];
+// DW = waves per workgroup: 16 for NB <= 2, fewer for more batch tiles (register budget per wave)
+template <int NB, int DW>
+__global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
+    __shared__ float Gl[DW * NB * 16 * 17];
     const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     auto wrow = [&](int c) -> int {
         if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
@@ -199,17 +204,20 @@ __global__ __launch_bounds__(NT) void skinny_direct_kernel(SkinnyArgs a) {
         return r;
     };
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // global k-step index over the concatenated segments; wave w takes k-steps w, w+DW, ...
+    int ks_base = 0;
     for (int sidx = 0; sidx < a.ns; ++sidx) {
         const Seg& sg = a.seg[sidx];
         const int nks = (sg.K + 31) / 32;
         const float* __restrict__ wp = row >= 0 ? sg.w + (long)row * sg.ldw : nullptr;
-        // wave w takes k-steps w, w+4, ...; two k-steps are in flight per iteration
-        for (int ks = wave; ks < nks; ks += 8) {
+        int first = (wave - ks_base % DW + DW) % DW;          // first local k-step of this wave in the segment
+        for (int ks = first; ks < nks; ks += 2 * DW) {
             float4 bw[2][2], ax[2][NB][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int k = (ks + 4 * u) * 32 + fq * 8;
-                const bool live = (ks + 4 * u) < nks;
+                const int kk = ks + DW * u;
+                const int k = kk * 32 + fq * 8;
+                const bool live = kk < nks;
                 bw[u][0] = (live && wp && k < sg.K) ? *(const float4*)(wp + k) : z4;
                 bw[u][1] = (live && wp && k + 4 < sg.K) ? *(const float4*)(wp + k + 4) : z4;
 #pragma unroll
@@ -228,13 +236,14 @@ __global__ __launch_bounds__(NT) void skinny_direct_kernel(SkinnyArgs a) {
                     acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack(ax[u][bt][0], ax[u][bt][1]), bf, acc[bt], 0, 0, 0);
             }
         }
+        ks_base += nks;
     }
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    skinny_epilogue<NB>(a, Gl, blk);
+    skinny_epilogue<NB, DW>(a, Gl, blk);
 }
 
 constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU
@@ -289,7 +298,7 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
         }
         if (ok) {
             const int grid_d = mode == 2 ? (C + 3) / 4 : (N + 15) / 16;
-            LAS_NB_SWITCH(NB, { hipLaunchKernelGGL((skinny_direct_kernel<NB_>), dim3(grid_d), dim3(NT), 0, st, a); LAS_LAUNCH_OK(); return LAS_OK; });
+            LAS_NB_SWITCH(NB, { constexpr int DW_ = NB_ <= 2 ? 16 : (NB_ == 4 ? 8 : 4); hipLaunchKernelGGL((skinny_direct_kernel<NB_, DW_>), dim3(grid_d), dim3(DW_ * 64), 0, st, a); LAS_LAUNCH_OK(); return LAS_OK; });
         }
     }
     int KC = 0, NCK = 0;

@@ -158,7 +158,7 @@ class DecoderFn(torch.autograd.Function):
                   demb=torch.empty(V, C, **f32))
         if loc:
             Bw.update(extra=torch.empty(2, B, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
-                      acc=torch.empty(B * nch, accf, **f32))
+                      acc=torch.empty(B, accf, **f32))
         else:
             Bw['de'] = torch.empty(L, B, Tp, **f32)
         bw = DecBwdState()

@@ -157,7 +157,7 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
     float* da;                      /* [B][Tp] scratch */
     float* extra;                   /* loc: [2][B][Tp] d loss / d prev_att carried between steps */
     float* dpsi;                    /* loc: [B][Tp][A] accumulated d loss / d psi(enc) */
-    float* acc;                     /* loc: [B*las_decoder_att_chunks(Tp)][las_decoder_loc_acc_floats(A)] partial sums:
+    float* acc;                     /* loc: [B][las_decoder_loc_acc_floats(A)] per-utterance partial sums:
                                        d w_lp [A*10] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
     float* demb;                    /* [V][C] d loss / d embed.weight */
 } las_dec_bwd_state;

@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the package (no GPU, no compute calls into the HIP library)."""
+import importlib
+import os
+import pickle
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pkg = importlib.import_module('end-to-end-asr-pytorch_amd')
+synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
+dataset = importlib.import_module('end-to-end-asr-pytorch_amd.dataset')
+post = importlib.import_module('end-to-end-asr-pytorch_amd.postprocess')
+asr = importlib.import_module('end-to-end-asr-pytorch_amd.asr')
+ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+
+TIMIT_YAML = """
+asr_model:
+  optimizer: {type: 'Adam', learning_rate: 0.0001, joint_ctc: 0.0}
+  encoder: {enc_type: 'BiRNN', sample_rate: '2_2_1', sample_style: 'concat', dim: '256_256_256', dropout: '0_0_0', rnn_cell: 'LSTM'}
+  attention: {att_mode: 'dot', dim: 256, proj: True, num_head: 1}
+  decoder: {dim: 256, layer: 1, dropout: 0, rnn_cell: 'LSTMCell'}
+"""
+
+
+def test_param_count_matches_reference_timit_config():
+    """SURVEY.md §8 A2 [probe]: the reference's Seq2Seq for config/timit_example.yaml (D=39, V=63) has 9,500,991
+    parameters; the same YAML keys must size the same tensors here."""
+    cfg = yaml.safe_load(TIMIT_YAML)['asr_model']
+    shapes = asr.param_shapes(torch.zeros(8, 300, 39), 63, cfg)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 9500991
+    assert shapes['encoder.layer0.layer.weight_ih_l0_reverse'] == (1024, 39)
+    assert shapes['encoder.proj1.weight'] == (1024, 1024)
+    assert shapes['decoder.layer0.weight_ih'] == (1024, 768)
+    assert shapes['char_trans.weight'] == (63, 256)
+
+
+def test_config_surface_errors():
+    cfg = yaml.safe_load(TIMIT_YAML)['asr_model']
+    bad = dict(cfg, encoder=dict(cfg['encoder'], dim='256_256'))
+    with pytest.raises(AssertionError):
+        asr.param_shapes(torch.zeros(1, 10, 39), 63, bad)
+    bad = dict(cfg, encoder=dict(cfg['encoder'], enc_type='VGGBiRNN'))
+    with pytest.raises(NotImplementedError):
+        asr.param_shapes(torch.zeros(1, 10, 39), 63, bad)
+    bad = dict(cfg, attention=dict(cfg['attention'], att_mode='foo'))
+    with pytest.raises(ValueError):
+        asr.param_shapes(torch.zeros(1, 10, 39), 63, bad)
+
+
+def test_flat_param_layout_alignment():
+    cfg = yaml.safe_load(TIMIT_YAML)['asr_model']
+    cfg['encoder'].update(dim='8_8_8')
+    cfg['attention'].update(dim=6, att_mode='loc')
+    cfg['decoder'].update(dim=8)
+    m = asr.Seq2Seq(torch.zeros(2, 20, 5), 9, cfg, device='cpu')
+    for name, (off, k, shape) in m.param_slices.items():
+        if not name.endswith('_reverse'):
+            assert off % 64 == 0, name
+    # per-direction twins are adjacent so the kernel-facing concatenation is a plain view
+    o0, k0, _ = m.param_slices['encoder.layer0.layer.weight_ih_l0']
+    o1, _, _ = m.param_slices['encoder.layer0.layer.weight_ih_l0_reverse']
+    assert o1 == o0 + k0
+    cat = m._cat('encoder.layer0.layer', 'weight_ih', (2 * 32, 5))
+    assert torch.equal(cat[:32], m.P('encoder.layer0.layer.weight_ih_l0').data)
+    assert torch.equal(cat[32:], m.P('encoder.layer0.layer.weight_ih_l0_reverse').data)
+    assert m.P('decoder.layer0.bias_ih').data[8:16].eq(1).all()        # forget-gate bias = 1 (asr.py:144-153)
+    assert m.P('embed.weight').grad.data_ptr() == m.flat_grads.data_ptr() + 4 * m.param_slices['embed.weight'][0]
+    names = [n for n, _ in m.named_parameters()]
+    assert 'attention.loc_conv.weight' in names and 'ctc_layer.weight' not in names
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(pkg.LasError):
+        ops.infer_lengths(torch.zeros(2, 3, 4))
+
+
+def test_synthetic_batch_contract():
+    x, y, lens = synth.make_batch(3, 6, 50, 7, 11, 9, time_reduction=4)
+    assert x.shape == (6, 50, 7) and lens == sorted(lens, reverse=True) and lens[0] == 50
+    for b, l in enumerate(lens):
+        assert (x[b, l:] == 0).all() and (x[b, :l].abs().sum(-1) != 0).all()
+        n = int((y[b] != 0).sum()) - 1
+        assert y[b, 0] == 0 and y[b, n + 1] == 1 and (y[b, n + 2:] == 0).all() and (y[b, 1:n + 1] >= 2).all()
+        assert 2 * (n + 1) + 1 <= l // 4 + 2          # CTC-feasible with the <eos>
+    x2, y2, _ = synth.make_batch(3, 6, 50, 7, 11, 9, time_reduction=4)
+    assert torch.equal(x, x2) and torch.equal(y, y2)
+    assert synth.total_downsample('2_2_1_1_1') == 4
+
+
+def test_timit_buckets(tmp_path):
+    rng = np.random.RandomState(0)
+    xs = [rng.randn(n, 4).astype(np.float32) for n in [5, 9, 7, 3, 8]]
+    ys = [[0, 2, 3, 1], [0, 4, 1], [0, 2, 2, 2, 1], [0, 5, 1], [0, 3, 1]]
+    pickle.dump(xs, open(tmp_path / 'train_x.pkl', 'wb'))
+    pickle.dump(ys, open(tmp_path / 'train_y.pkl', 'wb'))
+    ds = dataset.TimitBuckets(str(tmp_path), ['train'], 2)
+    assert len(ds) == 3
+    x0, y0 = ds.get(0)
+    assert x0.shape == (2, 9, 4) and np.allclose(x0[0], xs[1]) and np.allclose(x0[1, :8], xs[4]) and (x0[1, 8:] == 0).all()
+    assert y0.tolist() == [[0, 4, 1], [0, 3, 1]]
+    batches = list(ds)
+    assert batches[0][0].shape[0] == 1 and batches[0][0].dim() == 4 and batches[0][1].dim() == 3
+
+
+def test_libri_half_batch_rule(tmp_path):
+    import pandas as pd
+    rows = []
+    for i, n in enumerate([900, 850, 500, 400]):
+        np.save(tmp_path / f'u{i}.npy', np.ones((n, 3), np.float32))
+        rows.append(dict(file_path=f'u{i}.npy', length=n, label='0_5_6_1'))
+    pd.DataFrame(rows).to_csv(tmp_path / 'train.csv', index=False)
+    ds = dataset.LibriBuckets(str(tmp_path), ['train'], 2)
+    assert [len(b) for b in ds.items] == [1, 1, 2]        # first bucket exceeds 800 frames -> halved (dataset.py:88-92)
+    x, y = ds.get(2)
+    assert x.shape == (2, 500, 3) and y.tolist() == [[0, 5, 6, 1], [0, 5, 6, 1]]
+
+
+def test_mapper_and_metrics():
+    m = post.Mapper(mapping={'<sos>': 0, '<eos>': 1, 'a': 2, 'b': 3, 'c': 4})
+    assert m.unit == 'char' and m.get_dim() == 5
+    assert m.translate([2, 3, 1, 4], return_string=True) == 'ab'
+    assert post.edit_distance('kitten', 'sitting') == 3
+    assert post.cal_acc(np.array([[2, 3, 4], [2, 2, 2]]), np.array([[2, 3, 0], [3, 2, 1]])) == pytest.approx((1.0 + 1 / 3) / 2)
+    ph = post.Mapper(mapping={'<sos>': 0, '<eos>': 1, 'ao': 2, 'h#': 3})
+    assert ph.unit == 'phone' and ph.translate([2, 3, 1], return_string=True) == 'aa h# '
+    assert post.cal_cer(np.array([[2, 3, 1]]), np.array([[2, 2, 1]]), m) == 1.0
+
+
+def test_main_cli_flags():
+    import main
+    a = main.parse(['--config', 'config/x.yaml', '--seed', '3', '--cpu', '--no-msg'])
+    assert a.config == 'config/x.yaml' and a.seed == 3 and a.gpu is False and a.verbose is False
+    assert a.logdir == 'log/' and a.ckpdir == 'result/' and a.njobs == 1 and not a.test and not a.rnnlm

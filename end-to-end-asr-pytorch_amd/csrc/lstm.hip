@@ -30,11 +30,16 @@ constexpr int NT = 256;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr size_t MIN_LDS = 84 * 1024;            // > 80 KiB: at most one workgroup per CU
 
+constexpr int MAX_SLICES = 16;
 struct SyncWords {          // zeroed by hipMemsetAsync before every launch
-    unsigned cnt[2];        // arrivals per direction
-    unsigned abort_;        // set on spin timeout
-    unsigned pad;
+    unsigned cnt[2 * MAX_SLICES];   // arrivals per (direction, batch slice)
+    unsigned abort_;                // set on spin timeout
+    unsigned pad[3];
 };
+
+// one-v_exp activations for the cell pointwise (abs err ~1e-7; the recurrence is fp32 throughout)
+__device__ __forceinline__ float fsig(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
 
 // One lane polls `cnt >= target` (sc1 loads); returns false on timeout / abort.
 __device__ __forceinline__ bool wait_counter(unsigned* cnt, unsigned target, unsigned* abort_word) {
@@ -92,6 +97,7 @@ __device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int row
 
 struct LstmArgs {
     int T, B, H, ND, U, G;
+    int NS, Bs;               // batch slices (independent sub-recurrences) and rows per slice
     int sr, concat, T_out, F_out;
     int y_is_hf;
 };
@@ -119,7 +125,8 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     const int H = a.H, B = a.B, U = a.U, ND = a.ND;
     const int Kp = (H + KSTEP - 1) / KSTEP * KSTEP, ld = Kp + VEC;
     const int Hx = (H + VEC - 1) / VEC * VEC;           // exchange row stride (pad columns are caller-zeroed)
-    const int d = blockIdx.x / a.G, g = blockIdx.x % a.G, j0 = g * U;
+    const int d = blockIdx.x / (a.G * a.NS), g = (blockIdx.x % (a.G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * U;
+    const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);  // my batch slice: rows [b0, b0+Bl)
     T* Wl = (T*)smem;                                   // [4][16][ld]
     T* Hl = Wl + 4 * 16 * ld;                           // [NB*16][ld]
     float* Gl = (float*)(Hl + NB * 16 * ld);            // [4][NB*16][17]
@@ -134,10 +141,10 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
     }
     for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) Hl[i] = (T)0;
-    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < B ? lens[i] : 0;
+    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     __syncthreads();
 
-    // ---- my pointwise elements: pairs (b, n..n+1)
+    // ---- my pointwise elements: pairs (b, n..n+1); eb = row within the slice
     constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
     const int half = U / 2;
     float c_state[PP][2];
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     for (int p = 0; p < PP; ++p) {
         const int e = threadIdx.x + p * NT;
         eb[p] = e / half; en[p] = (e % half) * 2;
-        ev[p] = (e < NB * 16 * half) && eb[p] < B && (j0 + en[p] < H);
+        ev[p] = (e < NB * 16 * half) && eb[p] < Bl && (j0 + en[p] < H);
         c_state[p][0] = c_state[p][1] = 0.f;
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi)
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * 4 * H;
-    unsigned* cnt = &sync->cnt[d];
+    unsigned* cnt = &sync->cnt[d * MAX_SLICES + bs];
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? s : a.T - 1 - s;
@@ -171,12 +178,12 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         for (int p = 0; p < PP; ++p)
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                xp[p][gi] = ev[p] ? *(const float2*)(xproj + ((long)t * B + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p])
+                xp[p][gi] = ev[p] ? *(const float2*)(xproj + ((long)t * B + b0 + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p])
                                   : make_float2(0.f, 0.f);
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
         if (s > 0) {
             if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            pull_tile_sc1<T, VEC>(hx + ((long)d * a.T + tp) * B * Hx, B, Hx, Hl, ld);
+            pull_tile_sc1<T, VEC>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hl, ld);
         }
         __syncthreads();
         // (d) gate pre-activations: wave w <-> gate w
@@ -190,42 +197,48 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
         __syncthreads();
-        // (f) pointwise cell update, publish h_t
+        // (f) pointwise cell update; publish h_t FIRST, signal, then write what only the backward pass reads
+        float hv[PP][2], gv[PP][4][2];
 #pragma unroll
         for (int p = 0; p < PP; ++p) {
             if (!ev[p]) continue;
-            const int b = eb[p], n = en[p], j = j0 + n;
-            const bool m = t < lensl[b];
-            float hv[2], gv[4][2];
+            const int bl = eb[p], n = en[p], j = j0 + n;
+            const bool m = t < lensl[bl];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float pi = Gl[(0 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][0].y : xp[p][0].x) + bias[p][0][q];
-                const float pf = Gl[(1 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][1].y : xp[p][1].x) + bias[p][1][q];
-                const float pg = Gl[(2 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][2].y : xp[p][2].x) + bias[p][2][q];
-                const float po = Gl[(3 * NB * 16 + b) * 17 + n + q] + (q ? xp[p][3].y : xp[p][3].x) + bias[p][3][q];
-                const float ig = sigmoidf_(pi), fg = sigmoidf_(pf), gg = tanhf(pg), og = sigmoidf_(po);
+                const float pi = Gl[(0 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][0].y : xp[p][0].x) + bias[p][0][q];
+                const float pf = Gl[(1 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][1].y : xp[p][1].x) + bias[p][1][q];
+                const float pg = Gl[(2 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][2].y : xp[p][2].x) + bias[p][2][q];
+                const float po = Gl[(3 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][3].y : xp[p][3].x) + bias[p][3][q];
+                const float ig = fsig(pi), fg = fsig(pf), gg = ftanh(pg), og = fsig(po);
                 const float cn = fg * c_state[p][q] + ig * gg;
-                const float hn = og * tanhf(cn);
+                const float hn = og * ftanh(cn);
                 const bool mq = m && (j + q < H);
                 c_state[p][q] = mq ? cn : c_state[p][q];
-                hv[q] = mq ? hn : 0.f;
-                gv[0][q] = mq ? ig : 0.f; gv[1][q] = mq ? fg : 0.f; gv[2][q] = mq ? gg : 0.f; gv[3][q] = mq ? og : 0.f;
+                hv[p][q] = mq ? hn : 0.f;
+                gv[p][0][q] = mq ? ig : 0.f; gv[p][1][q] = mq ? fg : 0.f; gv[p][2][q] = mq ? gg : 0.f; gv[p][3][q] = mq ? og : 0.f;
             }
-            st_pair_sc1(hx + (((long)d * a.T + t) * B + b) * Hx + j, hv[0], hv[1]);
+            st_pair_sc1(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p][0], hv[p][1]);
+        }
+        // (g) publish: only the exchange stores are outstanding here
+        block_signal(cnt);
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (!ev[p]) continue;
+            const int bl = eb[p], b = b0 + bl, j = j0 + en[p];
+            const bool m = t < lensl[bl];
             const long ro = (long)t * B + b;
-            *(float2*)(hf + ro * (ND * H) + d * H + j) = make_float2(hv[0], hv[1]);
+            *(float2*)(hf + ro * (ND * H) + d * H + j) = make_float2(hv[p][0], hv[p][1]);
             if (!a.y_is_hf) {
                 bool ok;
                 const long yo = y_offset(a, t, b, d, j, ok);
-                if (ok) *(float2*)(y + yo) = make_float2(hv[0], hv[1]);
+                if (ok) *(float2*)(y + yo) = make_float2(hv[p][0], hv[p][1]);
             }
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                *(float2*)(gates + ro * ND4H + d * 4 * H + gi * H + j) = make_float2(gv[gi][0], gv[gi][1]);
+                *(float2*)(gates + ro * ND4H + d * 4 * H + gi * H + j) = make_float2(gv[p][gi][0], gv[p][gi][1]);
             *(float2*)(cs + ro * (ND * H) + d * H + j) = make_float2(m ? c_state[p][0] : 0.f, m ? c_state[p][1] : 0.f);
         }
-        // (g) publish
-        block_signal(cnt);
     }
 }
 
@@ -244,7 +257,8 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     const int H = a.H, B = a.B, U = a.U, ND = a.ND, K4 = 4 * H;
     const int KC = K4p / NC;                              // chunk width; K4p = 4H zero-padded so KC % (4*KSTEP) == 0
     const int ldw = K4p + VEC, ldc = KC + VEC;
-    const int d = blockIdx.x / a.G, g = blockIdx.x % a.G, j0 = g * U;
+    const int d = blockIdx.x / (a.G * a.NS), g = (blockIdx.x % (a.G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * U;
+    const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
     T* Wl = (T*)smem;                                     // [16][ldw]   W_hh^T columns of my units
     T* Dl = Wl + 16 * ldw;                                // [NB*16][ldc] dgates_next chunk
     float* Gl = (float*)(Dl + NB * 16 * ldc);             // [4][NB*16][17] per-wave partial sums
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
         Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
     }
     for (int i = threadIdx.x; i < NB * 16 * ldc; i += NT) Dl[i] = (T)0;
-    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < B ? lens[i] : 0;
+    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     __syncthreads();
 
     constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
@@ -270,12 +284,12 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     for (int p = 0; p < PP; ++p) {
         const int e = threadIdx.x + p * NT;
         eb[p] = e / half; en[p] = (e % half) * 2;
-        ev[p] = (e < NB * 16 * half) && eb[p] < B && (j0 + en[p] < H);
+        ev[p] = (e < NB * 16 * half) && eb[p] < Bl && (j0 + en[p] < H);
         dc_carry[p][0] = dc_carry[p][1] = 0.f;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * K4, NDH = ND * H;
-    unsigned* cnt = &sync->cnt[d];
+    unsigned* cnt = &sync->cnt[d * MAX_SLICES + bs];
     const int kq = KC / KSTEP / 4;                        // k-steps per wave per chunk
 
     for (int s = 0; s < a.T; ++s) {
@@ -290,13 +304,13 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) sg[p][gi] = make_float2(0.f, 0.f);
             if (!ev[p]) continue;
-            const int b = eb[p], j = j0 + en[p];
-            if (t >= lensl[b]) continue;
+            const int bl = eb[p], b = b0 + bl, j = j0 + en[p];
+            if (t >= lensl[bl]) continue;
             const long ro = (long)t * B + b;
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) sg[p][gi] = *(const float2*)(gates + ro * ND4H + d * K4 + gi * H + j);
             sc[p] = *(const float2*)(cs + ro * NDH + d * H + j);
-            if (tp >= 0 && tp < lensl[b]) scp[p] = *(const float2*)(cs + ((long)tp * B + b) * NDH + d * H + j);
+            if (tp >= 0 && tp < lensl[bl]) scp[p] = *(const float2*)(cs + ((long)tp * B + b) * NDH + d * H + j);
             bool ok;
             const long yo = y_offset(a, t, b, d, j, ok);
             if (ok) sdy[p] = *(const float2*)(dy + yo);
@@ -307,14 +321,14 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
             if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            const T* src = dgx + ((long)d * a.T + tn) * B * K4;
+            const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
             for (int c = 0; c < NC; ++c) {
                 if (c > 0) __syncthreads();               // previous chunk fully consumed
                 // rows have stride K4 in memory, KC columns starting at c*KC
                 {
                     const int kreal = min(KC, K4 - c * KC);       // real (unpadded) columns of this chunk
-                    const int vpr = kreal / VEC, total = B * vpr;
-                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, B * K4 * (int)sizeof(T), 0x00020000);
+                    const int vpr = kreal / VEC, total = Bl * vpr;
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, Bl * K4 * (int)sizeof(T), 0x00020000);
                     for (int i = threadIdx.x; i < total; i += NT) {
                         const int r = i / vpr, cc = (i - r * vpr) * VEC;
                         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * K4 + c * KC + cc) * (int)sizeof(T), 0, 16);
@@ -331,38 +345,44 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
 #pragma unroll
             for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
         __syncthreads();
-        // (f) pointwise BPTT, publish dgates_t
+        // (f) pointwise BPTT; publish dgates_t FIRST, signal, then write the fp32 copy for the weight-gradient GEMMs
+        float dg[PP][4][2];
 #pragma unroll
         for (int p = 0; p < PP; ++p) {
             if (!ev[p]) continue;
-            const int b = eb[p], n = en[p], j = j0 + n;
-            const bool m = t < lensl[b];
-            float dg[4][2];
+            const int bl = eb[p], n = en[p], j = j0 + n;
+            const bool m = t < lensl[bl];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float dh_rec = Gl[(0 * NB * 16 + b) * 17 + n + q] + Gl[(1 * NB * 16 + b) * 17 + n + q] +
-                                     Gl[(2 * NB * 16 + b) * 17 + n + q] + Gl[(3 * NB * 16 + b) * 17 + n + q];
+                const float dh_rec = Gl[(0 * NB * 16 + bl) * 17 + n + q] + Gl[(1 * NB * 16 + bl) * 17 + n + q] +
+                                     Gl[(2 * NB * 16 + bl) * 17 + n + q] + Gl[(3 * NB * 16 + bl) * 17 + n + q];
                 const float ig = q ? sg[p][0].y : sg[p][0].x, fg = q ? sg[p][1].y : sg[p][1].x;
                 const float gg = q ? sg[p][2].y : sg[p][2].x, og = q ? sg[p][3].y : sg[p][3].x;
                 const float ct = q ? sc[p].y : sc[p].x, cp = q ? scp[p].y : scp[p].x;
                 const float dh = (q ? sdy[p].y : sdy[p].x) + dh_rec;
-                const float tc = tanhf(ct);
+                const float tc = ftanh(ct);
                 const float dc = dh * og * (1.f - tc * tc) + dc_carry[p][q];
                 const bool mq = m && (j + q < H);
-                dg[0][q] = mq ? dc * gg * ig * (1.f - ig) : 0.f;
-                dg[1][q] = mq ? dc * cp * fg * (1.f - fg) : 0.f;
-                dg[2][q] = mq ? dc * ig * (1.f - gg * gg) : 0.f;
-                dg[3][q] = mq ? dh * tc * og * (1.f - og) : 0.f;
+                dg[p][0][q] = mq ? dc * gg * ig * (1.f - ig) : 0.f;
+                dg[p][1][q] = mq ? dc * cp * fg * (1.f - fg) : 0.f;
+                dg[p][2][q] = mq ? dc * ig * (1.f - gg * gg) : 0.f;
+                dg[p][3][q] = mq ? dh * tc * og * (1.f - og) : 0.f;
                 dc_carry[p][q] = mq ? dc * fg : 0.f;
             }
-            const long ro = (long)t * B + b;
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                st_pair_sc1(dgx + (((long)d * a.T + t) * B + b) * K4 + gi * H + j, dg[gi][0], dg[gi][1]);
-                *(float2*)(dgf + ro * ND4H + d * K4 + gi * H + j) = make_float2(dg[gi][0], dg[gi][1]);
-            }
+            for (int gi = 0; gi < 4; ++gi)
+                st_pair_sc1(dgx + (((long)d * a.T + t) * B + b0 + bl) * K4 + gi * H + j, dg[p][gi][0], dg[p][gi][1]);
         }
         block_signal(cnt);
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (!ev[p]) continue;
+            const long ro = (long)t * B + b0 + eb[p];
+            const int j = j0 + en[p];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+                *(float2*)(dgf + ro * ND4H + d * K4 + gi * H + j) = make_float2(dg[p][gi][0], dg[p][gi][1]);
+        }
     }
 }
 
@@ -387,12 +407,16 @@ constexpr size_t LDS_CAP = 160 * 1024;
 int check_common(int T, int B, int H, int ND, int sr) {
     if (T <= 0 || B <= 0 || H <= 0 || (ND != 1 && ND != 2) || sr < 1) return LAS_E_BADARG;
     if (H % 2 != 0) return LAS_E_UNSUPPORTED;          // pair stores / float2 accesses
-    if (las_pick_nb(B) == 0) return LAS_E_UNSUPPORTED;
     return LAS_OK;
 }
 
 void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int concat) {
     a.T = T; a.B = B; a.H = H; a.ND = ND; a.U = U; a.G = (H + U - 1) / U;
+    // batch slices: independent sub-recurrences of <= 16 rows each, as many as the chip has room for
+    int ns = (B + 11) / 12;
+    while (ns > 1 && ((long)ND * a.G * ns > 256 || ns > MAX_SLICES)) --ns;
+    a.Bs = (B + ns - 1) / ns;
+    a.NS = (B + a.Bs - 1) / a.Bs;
     a.sr = sr; a.concat = concat;
     if (sr == 1) { a.T_out = T; a.F_out = ND * H; }
     else if (concat) { a.T_out = T / sr; a.F_out = sr * ND * H; }
@@ -406,7 +430,7 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
                SyncWords* sync, int* status) {
     auto k = lstm_fwd_kernel<PREC, NB>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.ND * a.G), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+    hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (typename CT<PREC>::T*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
@@ -417,7 +441,7 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
                int* status) {
     auto k = lstm_bwd_kernel<PREC, NB>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.ND * a.G), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
+    hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
                        (typename CT<PREC>::T*)dgx, dgf, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
@@ -440,14 +464,17 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     LAS_CHECK_ARG(xproj && b_ih && b_hh && w_hh && lens && y && hf && hx && gates && cs && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
-    const int NB = las_pick_nb(B);
+    if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     int U = 16;
-    size_t lds = fwd_lds(prec, H, NB);
-    if (lds > LDS_CAP || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
-    // use more, smaller slices when the chip has room (shorter MFMA chains per step)
+    if (ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    // use more, smaller unit slices when the chip has room (shorter MFMA chains per step)
     if (ND * ((H + 7) / 8) <= 256 && H >= 512) U = 8;
     LstmArgs a;
     fill_args(a, T, B, H, ND, U, sr, concat);
+    const int NB = las_pick_nb(a.Bs);
+    if (NB == 0) return LAS_E_UNSUPPORTED;
+    size_t lds = fwd_lds(prec, H, NB);
+    if (lds > LDS_CAP) return LAS_E_UNSUPPORTED;
     a.y_is_hf = (y == hf);
     if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
     if (lds < MIN_LDS) lds = MIN_LDS;
@@ -467,15 +494,16 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     LAS_CHECK_ARG(dy && gates && cs && w_hh && lens && dgx && dgf && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
-    const int NB = las_pick_nb(B);
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
+    LstmArgs a;
+    fill_args(a, T, B, H, ND, 16, sr, concat);
+    const int NB = las_pick_nb(a.Bs);
+    if (NB == 0) return LAS_E_UNSUPPORTED;
     const int ks = prec == LAS_PREC_BF16 ? 32 : 16;
     const int K4p = bwd_k4p(prec, H);
     int NC = 1;                                                  // chunks must keep whole k-steps per wave and be unpadded if >1
     while (NC <= 8 && (bwd_lds(prec, H, NB, NC) > LDS_CAP || (K4p / NC) % (4 * ks) != 0 || (NC > 1 && K4p != 4 * H))) NC *= 2;
     if (NC > 8 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
-    LstmArgs a;
-    fill_args(a, T, B, H, ND, 16, sr, concat);
     size_t lds = bwd_lds(prec, H, NB, NC);
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;

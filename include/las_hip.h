@@ -69,7 +69,7 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).
  * bwd: dy [T_out][B][F_out] -> dgf [T][B][ND*4H] (= d loss / d xproj, fp32) and dgx [ND][T][B][4H]
  * (exchange copy, operand type).  dW_ih, dW_hh, db, dx follow from dgf through las_gemm / las_colsum.
- * Limits: H % 2 == 0, B <= 128, ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
+ * Limits: H % 2 == 0, B <= 2048 (the batch is cut into independent slices of <= 128 rows, normally ~12), ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
 void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
 size_t las_lstm_sync_bytes(void);
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     const int t1 = min(t0 + a.TC, a.Tp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* q_l = sm;                                 // [A]
-    for (int i = threadIdx.x; i < a.A; i += 256) q_l[i] = a.q[(long)b * a.A + i];
+    fill_batched<2>(a.q + (long)b * a.A, a.A, [&](int i, float v) { q_l[i] = v; });
     if (!LOC) {
         __syncthreads();
         for (int t = t0 + wave; t < t1; t += 4) {
@@ -81,12 +81,16 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
     float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
     float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]
-    for (int i = threadIdx.x; i < a.A; i += 256) we_l[i] = a.w_e[i];
-    for (int i = threadIdx.x; i < LOC_C * a.A; i += 256) { const int aa = i / LOC_C, c = i % LOC_C; wlp_l[c * a.A + aa] = a.w_lp[i]; }
-    for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) cw_l[i] = a.conv_w[i];
-    for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
-        const int t = t0 - LOC_K + i;
-        prev_l[i] = (t >= 0 && t < a.Tp) ? a.prev[(long)b * a.Tp + t] : 0.f;
+    fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
+    fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
+    fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+    {
+        const float* __restrict__ pr = a.prev + (long)b * a.Tp;
+        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
+            const int t = t0 - LOC_K + i;
+            const float v = pr[min(max(t, 0), a.Tp - 1)];
+            prev_l[i] = (t >= 0 && t < a.Tp) ? v : 0.f;
+        }
     }
     __syncthreads();
     // location features f[c][t] = sum_k w[c][k] * prev[t + k - K]
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
             for (int i0 = lane; i0 < a.A; i0 += 256) {          // 4 independent psi loads in flight per lane
                 float pv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pv[k] = (i0 + 64 * k < a.A) ? p[i0 + 64 * k] : 0.f;
+                for (int k = 0; k < 4; ++k) pv[k] = p[min(i0 + 64 * k, a.A - 1)];     // unconditional, clamped
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int i = i0 + 64 * k;

@@ -150,17 +150,23 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]  saved location features of this chunk
     float* df_l = f_l + LOC_C * a.TC;                // [10][TC]
     float* acc_l = df_l + LOC_C * a.TC;              // [A][12] = {dq, dwe, dwlp[10]} summed over the block (LDS atomics)
-    for (int i = threadIdx.x; i < a.A; i += 256) we_l[i] = a.w_e[i];
-    for (int i = threadIdx.x; i < LOC_C * a.A; i += 256) { const int aa = i / LOC_C, c = i % LOC_C; wlp_l[c * a.A + aa] = a.w_lp[i]; }
-    for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) cw_l[i] = a.conv_w[i];
-    for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
-        const int t = t0 - LOC_K + i;
-        prev_l[i] = (t >= 0 && t < a.Tp) ? a.prev[(long)b * a.Tp + t] : 0.f;
-    }
-    for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
-        const int c = i / a.TC, tt = i % a.TC;
-        f_l[i] = (tt < tcv) ? a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] : 0.f;
-        df_l[i] = 0.f;
+    fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
+    fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
+    fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+    {
+        const float* __restrict__ pr = a.prev + (long)b * a.Tp;
+        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
+            const int t = t0 - LOC_K + i;
+            const float v = pr[min(max(t, 0), a.Tp - 1)];
+            prev_l[i] = (t >= 0 && t < a.Tp) ? v : 0.f;
+        }
+        const float* __restrict__ fp = a.f + (long)b * LOC_C * a.Tp;
+        for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
+            const int c = i / a.TC, tt = i - c * a.TC;
+            const float v = fp[(long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
+            f_l[i] = (tt < tcv) ? v : 0.f;
+            df_l[i] = 0.f;
+        }
     }
     for (int i = threadIdx.x; i < a.A * 12; i += 256) acc_l[i] = 0.f;
     __syncthreads();
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < AI; ++k) {
             const int i = lane + 64 * k;
-            sv[k] = i < a.A ? sp[i] : 0.f;
-            dpv[k] = i < a.A ? dp[i] : 0.f;
+            sv[k] = sp[min(i, a.A - 1)];           // unconditional, clamped; masked where used
+            dpv[k] = dp[min(i, a.A - 1)];
         }
 #pragma unroll
         for (int k = 0; k < AI; ++k) {

@@ -61,6 +61,32 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return r;
 }
 
+// 16-byte load the compiler keeps as ONE global_load_dwordx4: the pointer is asserted aligned and the load is
+// unconditional.  Mask by selecting on the DATA afterwards (v = ok ? v : 0): a `ok ? *p : 0` select makes hipcc
+// branch around every load, split it into dwords and wait per element (cdna_hip_programming.md, trap (c)).
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    return *reinterpret_cast<const float4*>(__builtin_assume_aligned(p, 16));
+}
+__device__ __forceinline__ float4 sel4(bool ok, const float4& v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// put(i, src[i]) for i in [0,n): U independent loads per thread are issued before the first put, so a fill costs
+// ceil(n / (threads*U)) memory round trips instead of one per element-stride.  Loads are unconditional from clamped
+// indices (see ldg4 above for why).
+template <int U, typename F>
+__device__ __forceinline__ void fill_batched(const float* __restrict__ src, int n, F put) {
+    const int nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += nt * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[min(i0 + u * nt, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * nt < n) put(i0 + u * nt, v[u]);
+    }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ---------------------------------------------------------------- bf16 helpers

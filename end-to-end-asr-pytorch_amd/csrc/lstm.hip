@@ -80,18 +80,29 @@ __device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
     __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Pull a [rows x cols] row-major tile of T (published by other CUs) into LDS rows of stride `ld`,
-// 16 bytes per lane per load, sc1 (L1 bypass).  cols % VEC == 0; src 16-B aligned.
-template <typename T, int VEC>
-__device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int rows, int cols, T* __restrict__ lds,
-                                              int ld) {
+// Pull a [rows x cols] tile (row stride `src_ld` elements, published by other CUs) into LDS rows of stride `ld`:
+// 16 bytes per lane per load, sc1 (L1 bypass).  All of a thread's loads (up to 8) are issued before the first LDS
+// write; out-of-range lanes read through the buffer descriptor's bounds check (returns 0, no branch).
+template <typename T, int VEC, int U>
+__device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int rows, int cols, int src_ld, int col0,
+                                              T* __restrict__ lds, int ld) {
     const int vpr = cols / VEC;                                  // vectors per row
     const int total = rows * vpr;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows * cols * (int)sizeof(T), 0x00020000);
-    for (int i = threadIdx.x; i < total; i += NT) {
-        const int r = i / vpr, c = (i - r * vpr) * VEC;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * cols + c) * (int)sizeof(T), 0, 16);
-        *(u32x4*)(lds + r * ld + c) = v;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows * src_ld * (int)sizeof(T), 0x00020000);
+    for (int i0 = threadIdx.x; i0 < total; i0 += NT * U) {
+        u32x4 v[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * NT;
+            const int r = i / vpr, c = (i - r * vpr) * VEC;
+            dst[u] = i < total ? r * ld + c : -1;
+            const int off = i < total ? (r * src_ld + col0 + c) * (int)sizeof(T) : 0x7ffffff0;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (dst[u] >= 0) *(u32x4*)(lds + dst[u]) = v[u];
     }
 }
 
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
         if (s > 0) {
             if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            pull_tile_sc1<T, VEC>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hl, ld);
+            pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
         }
         __syncthreads();
         // (d) gate pre-activations: wave w <-> gate w
@@ -324,17 +335,8 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
             const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
             for (int c = 0; c < NC; ++c) {
                 if (c > 0) __syncthreads();               // previous chunk fully consumed
-                // rows have stride K4 in memory, KC columns starting at c*KC
-                {
-                    const int kreal = min(KC, K4 - c * KC);       // real (unpadded) columns of this chunk
-                    const int vpr = kreal / VEC, total = Bl * vpr;
-                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, Bl * K4 * (int)sizeof(T), 0x00020000);
-                    for (int i = threadIdx.x; i < total; i += NT) {
-                        const int r = i / vpr, cc = (i - r * vpr) * VEC;
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (r * K4 + c * KC + cc) * (int)sizeof(T), 0, 16);
-                        *(u32x4*)(Dl + r * ldc + cc) = v;
-                    }
-                }
+                // rows have stride K4 in memory; this chunk = real columns [c*KC, c*KC + kreal)
+                pull_tile_sc1<T, VEC, 8>(src, Bl, min(KC, K4 - c * KC), K4, c * KC, Dl, ldc);
                 __syncthreads();
                 // A = Dl rows (batch) x k ; B = Wl rows (unit) x k, offset to this chunk/wave quarter
                 mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);

@@ -203,37 +203,43 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         r[4] = (short)f2bf(hi.x); r[5] = (short)f2bf(hi.y); r[6] = (short)f2bf(hi.z); r[7] = (short)f2bf(hi.w);
         return r;
     };
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // global k-step index over the concatenated segments; wave w takes k-steps w, w+DW, ...
+    // Every load is unconditional from a clamped (always valid) address; out-of-range pieces are zeroed on the data.
+    const int rowc = row >= 0 ? row : 0;
     int ks_base = 0;
     for (int sidx = 0; sidx < a.ns; ++sidx) {
         const Seg& sg = a.seg[sidx];
-        const int nks = (sg.K + 31) / 32;
-        const float* __restrict__ wp = row >= 0 ? sg.w + (long)row * sg.ldw : nullptr;
+        const int nks = (sg.K + 31) / 32, kmax = sg.K - 4;
+        const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
         int first = (wave - ks_base % DW + DW) % DW;          // first local k-step of this wave in the segment
         for (int ks = first; ks < nks; ks += 2 * DW) {
             float4 bw[2][2], ax[2][NB][2];
+            bool okw[2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int kk = ks + DW * u;
-                const int k = kk * 32 + fq * 8;
-                const bool live = kk < nks;
-                bw[u][0] = (live && wp && k < sg.K) ? *(const float4*)(wp + k) : z4;
-                bw[u][1] = (live && wp && k + 4 < sg.K) ? *(const float4*)(wp + k + 4) : z4;
+                const int k = (ks + DW * u) * 32 + fq * 8;
+                okw[u][0] = row >= 0 && k < sg.K;
+                okw[u][1] = row >= 0 && k + 4 < sg.K;
+                bw[u][0] = ldg4(wp + min(k, kmax));
+                bw[u][1] = ldg4(wp + min(k + 4, kmax));
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
-                    const int b = bt * 16 + fr;
-                    const float* xp = sg.x + (long)b * sg.ldx + k;
-                    ax[u][bt][0] = (live && b < a.B && k < sg.K) ? *(const float4*)xp : z4;
-                    ax[u][bt][1] = (live && b < a.B && k + 4 < sg.K) ? *(const float4*)(xp + 4) : z4;
+                    const int b = min(bt * 16 + fr, a.B - 1);
+                    const float* xp = sg.x + (long)b * sg.ldx;
+                    ax[u][bt][0] = ldg4(xp + min(k, kmax));
+                    ax[u][bt][1] = ldg4(xp + min(k + 4, kmax));
                 }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const bf16x8 bf = pack(bw[u][0], bw[u][1]);
+                const int k = (ks + DW * u) * 32 + fq * 8;
+                const bf16x8 bf = pack(sel4(okw[u][0], bw[u][0]), sel4(okw[u][1], bw[u][1]));
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt)
-                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack(ax[u][bt][0], ax[u][bt][1]), bf, acc[bt], 0, 0, 0);
+                for (int bt = 0; bt < NB; ++bt) {
+                    const bool okb = bt * 16 + fr < a.B;
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        pack(sel4(okb && k < sg.K, ax[u][bt][0]), sel4(okb && k + 4 < sg.K, ax[u][bt][1])), bf, acc[bt], 0, 0, 0);
+                }
             }
         }
         ks_base += nks;

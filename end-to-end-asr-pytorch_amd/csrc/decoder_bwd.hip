@@ -10,6 +10,7 @@
 // Sums over the L steps that are plain contractions (dW of every Linear/LSTMCell, d enc, d psi in dot mode)
 // are left to ONE las_gemm each after the loop, on the buffers this call fills.
 #include "las_mma.h"
+#include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
                       long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
@@ -100,8 +101,10 @@ struct AttBwdArgs {
     const float* conv_w; const float* w_lp; const float* w_e;
     float* dpsi;              // [B][Tp][A] (+=, block-owned rows)
     float* extra_out;         // [B][Tp] (+=, atomics): d loss / d prev
-    float* acc;               // [B*NCH][acc_stride]: d w_lp [A*10] | d w_e [A] | d b_e [1] | pad | d conv [10*201]
+    float* acc;               // [B][acc_stride]: d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad | d conv [10*201]
     long acc_stride;
+    int dbg;                  // timing experiments only (LAS_DBG_ATT): bit0 skip main loop, bit1 skip acc flush,
+                              // bit2 skip conv backward, bit3 skip the LDS fills
 };
 
 // grid (NCH, B)
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     __shared__ float red[32];
     const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.dbg & 16) return;
     float* de_l = sm;                                // [TC]
     // softmax backward needs the full-row dot  sum_t a[t] * da[t]
     float dot = 0.f;
@@ -142,17 +146,21 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         return;
     }
     const int tcv = min(t1, len) - t0;               // valid frames in this chunk
-    if (tcv <= 0) return;                            // whole chunk beyond the utterance: nothing flows
+    if (tcv <= 0 || (a.dbg & 32)) return;                            // whole chunk beyond the utterance: nothing flows
     float* we_l = de_l + a.TC;                       // [A]
     float* wlp_l = we_l + a.A;                       // [10][A]
-    float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
+    float* cw_l = wlp_l + 48 * a.A;                  // [10][201]   (wlp_l region is 48A long: reused for the partials)
     float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
     float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]  saved location features of this chunk
     float* df_l = f_l + LOC_C * a.TC;                // [10][TC]
-    float* acc_l = df_l + LOC_C * a.TC;              // [A][12] = {dq, dwe, dwlp[10]} summed over the block (LDS atomics)
+    // per-wave partial sums {dq, dwe, dwlp[10]} laid out [wave][12][A] (lane-contiguous: conflict-free plain stores);
+    // the region starts on the w_lp tile, which is dead once the main loop is over
+    float* acc_l = wlp_l;
+    if (!(a.dbg & 8)) {
     fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
     fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
     fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+    }
     {
         const float* __restrict__ pr = a.prev + (long)b * a.Tp;
         for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
@@ -168,8 +176,8 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
             df_l[i] = 0.f;
         }
     }
-    for (int i = threadIdx.x; i < a.A * 12; i += 256) acc_l[i] = 0.f;
     __syncthreads();
+    if (a.dbg & 64) return;
     float dq_r[AI], dwe_r[AI], dwlp_r[AI][LOC_C];
 #pragma unroll
     for (int k = 0; k < AI; ++k) {
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
     }
     float dbe = 0.f;
-    for (int tt = wave; tt < tcv; tt += 4) {
+    for (int tt = wave; tt < ((a.dbg & 1) ? 0 : tcv); tt += 4) {
         const int t = t0 + tt;
         const float de = de_l[tt];
         dbe += de;
@@ -217,35 +225,37 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
             if (lane == 0) df_l[c * a.TC + tt] = v;
         }
     }
-    // ---- block reduction of the per-lane accumulators through LDS float atomics
+    // ---- block reduction of the per-lane accumulators: per-wave partials, then a summing pass
+    __syncthreads();                                 // every wave is done reading wlp_l
 #pragma unroll
     for (int k = 0; k < AI; ++k) {
         const int i = lane + 64 * k;
         if (i < a.A) {
-            float* o = acc_l + i * 12;
-            atomicAdd(&o[0], dq_r[k]); atomicAdd(&o[1], dwe_r[k]);
+            float* o = acc_l + (long)wave * 12 * a.A + i;
+            o[0] = dq_r[k]; o[a.A] = dwe_r[k];
 #pragma unroll
-            for (int c = 0; c < LOC_C; ++c) atomicAdd(&o[2 + c], dwlp_r[k][c]);
+            for (int c = 0; c < LOC_C; ++c) o[(2 + c) * a.A] = dwlp_r[k][c];
         }
     }
     dbe = wave_sum(dbe);
     if (lane == 0) red[wave] = dbe;
     __syncthreads();
     float* accg = a.acc + (long)b * a.acc_stride;      // one accumulator row per utterance (float atomics)
-    for (int i = threadIdx.x; i < a.A * 12; i += 256) {
-        const int aa = i / 12, j = i % 12;
-        const float v = acc_l[i];
+    for (int i = threadIdx.x; i < ((a.dbg & 2) ? 0 : a.A * 12); i += 256) {
+        const int j = i / a.A, aa = i - j * a.A;         // j-major: coalesced LDS reads and global atomics
+        const float v = acc_l[i] + acc_l[12 * a.A + i] + acc_l[24 * a.A + i] + acc_l[36 * a.A + i];
         if (j == 0) {
             const float qv = a.q[(long)b * a.A + aa];
             atomicAdd(&a.dq_pre[(long)b * a.A + aa], v * (1.f - qv * qv));
         } else if (j == 1) {
             atomicAdd(&accg[a.A * LOC_C + aa], v);
         } else {
-            atomicAdd(&accg[aa * LOC_C + (j - 2)], v);
+            atomicAdd(&accg[(j - 2) * a.A + aa], v);     // [c][a]: contiguous atomics per wave
         }
     }
     if (threadIdx.x == 0) atomicAdd(&accg[a.A * LOC_C + a.A], red[0] + red[1] + red[2] + red[3]);
     // ---- location conv backward
+    if (a.dbg & 4) return;
     // d prev[tau] += sum_c sum_{t in chunk} w[c][tau - t + K] * df[c][t]
     for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
         const int tau = t0 - LOC_K + i;
@@ -304,7 +314,9 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
     }
     size_t lds_e = sizeof(float) * (size_t)TC;
-    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC + (size_t)A * 12);
+    // [TC] de | [A] w_e | max([10A] w_lp, then [4][12][A] partials overlaid from here) ... the overlay may run over
+    // cw/prev/f/df, which must stay live for the conv backward, so it gets its own tail instead: size = 48A after w_e
+    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + 48 * (size_t)A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC);
     if (lds_e > 160 * 1024) return LAS_E_UNSUPPORTED;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first
@@ -345,6 +357,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
         a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e;
         a.dpsi = w.dpsi; a.extra_out = extra_out; a.acc = w.acc; a.acc_stride = acc_stride;
+        { static const char* e = getenv("LAS_DBG_ATT"); a.dbg = e ? atoi(e) : 0; }
         if (!loc) {
             hipLaunchKernelGGL((att_bwd_energy<false, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
         } else {

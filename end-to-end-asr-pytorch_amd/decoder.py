@@ -194,7 +194,7 @@ class DecoderFn(torch.autograd.Function):
             acc = Bw['acc']
             red = ops.colsum(acc, torch.empty(accf, **f32))
             off = ((A * 10 + A + 1 + 3) // 4) * 4
-            g['attention.loc_proj.weight'] = red[:A * 10].view(A, 10)
+            g['attention.loc_proj.weight'] = red[:A * 10].view(10, A).t().contiguous()
             g['attention.gen_energy.weight'] = red[A * 10:A * 10 + A].view(1, A)
             g['attention.gen_energy.bias'] = red[A * 10 + A:A * 10 + A + 1]
             g['attention.loc_conv.weight'] = red[off:off + 10 * 201].view(10, 1, 201)

@@ -158,7 +158,7 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
     float* extra;                   /* loc: [2][B][Tp] d loss / d prev_att carried between steps */
     float* dpsi;                    /* loc: [B][Tp][A] accumulated d loss / d psi(enc) */
     float* acc;                     /* loc: [B][las_decoder_loc_acc_floats(A)] per-utterance partial sums:
-                                       d w_lp [A*10] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
+                                       d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
     float* demb;                    /* [V][C] d loss / d embed.weight */
 } las_dec_bwd_state;
 int64_t las_decoder_loc_acc_floats(int A);

@@ -333,10 +333,14 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             int rc = las_skinny_launch(prec, dg, 4 * C, p->w_ihT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr,
                                        0, 0, B, Kx, nullptr, nullptr, 0, dx, Kx, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
             if (rc) return rc;
-            rc = las_skinny_launch(prec, dg, 4 * C, p->w_hhT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0,
-                                   0, B, C, nullptr, nullptr, 0, w.dh_carry + (long)l * BC, C, 0, 0, nullptr, nullptr, nullptr,
-                                   nullptr, st);
-            if (rc) return rc;
+            // recurrent carry dh_{l,t-1} = dgates * W_hh; layer 0 gets the attention-query path in the same product
+            // (second k-segment dq_pre_t * W_phi) and is therefore launched after the attention backward below
+            if (l > 0 && t > 0) {
+                rc = las_skinny_launch(prec, dg, 4 * C, p->w_hhT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0,
+                                       0, B, C, nullptr, nullptr, 0, w.dh_carry + (long)l * BC, C, 0, 0, nullptr, nullptr, nullptr,
+                                       nullptr, st);
+                if (rc) return rc;
+            }
         }
         // ---- attention of step t
         float* extra_in = loc ? w.extra + (long)(t & 1) * B * Tp : nullptr;
@@ -372,11 +376,12 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
 #undef LAS_ATT_GO
         }
         LAS_LAUNCH_OK();
-        // ---- query path: dh0_{t-1} += dq_pre_t * W_phi
+        // ---- dh0_{t-1} = dgates_{0,t} * W_hh + dq_pre_t * W_phi   (one two-segment product)
         if (t > 0) {
-            int rc = las_skinny_launch(prec, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A, nullptr, 0, nullptr, 0, 0, nullptr, 0,
-                                       nullptr, 0, 0, B, C, nullptr, nullptr, 0, w.dh_carry, C, 1, 0, nullptr, nullptr, nullptr,
-                                       nullptr, st);
+            const float* dg0 = w.dgates + (long)t * B * 4 * C;
+            int rc = las_skinny_launch(prec, dg0, 4 * C, p->w_hhT[0], 4 * C, 4 * C, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A,
+                                       nullptr, 0, nullptr, 0, 0, B, C, nullptr, nullptr, 0, w.dh_carry, C, 0, 0, nullptr, nullptr,
+                                       nullptr, nullptr, st);
             if (rc) return rc;
         }
     }

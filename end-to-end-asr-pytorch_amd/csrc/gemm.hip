@@ -25,73 +25,74 @@ template <typename T> __device__ __forceinline__ T cvt(float f);
 template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float f) { return f2bf(f); }
 template <> __device__ __forceinline__ float cvt<float>(float f) { return f; }
 
-// 4 consecutive source elements starting at p (stride 1), of which `cnt` (0..4) are in range.
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int cnt, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cnt >= 4 && vec) {
-        v = *(const float4*)p;
-    } else {
-        if (cnt > 0) v.x = p[0];
-        if (cnt > 1) v.y = p[1];
-        if (cnt > 2) v.z = p[2];
-        if (cnt > 3) v.w = p[3];
-    }
-    return v;
-}
-
 // Stage-in registers for one operand tile (128 rows x 32 k): 4 float4 per thread.
 // KCONT: element (r,k) at src[r*ld + k]; thread -> row = tid/8 + 32*p, k4 = (tid%8)*4.
 // else : element (r,k) at src[k*ld + r]; thread -> k = 4*(tid/32) + p, r4 = (tid%32)*4: a 4x4 block that is
 //        transposed in registers so the LDS writes are 4 consecutive k per row (8/16-byte stores).
-template <bool KCONT>
-__device__ __forceinline__ void g_load(float4 (&reg)[4], const float* __restrict__ src, long ld, int row0, int k0,
-                                       int rows, int K, bool vec) {
+// VEC (host-checked: 16-B aligned base, ld % 4 == 0, and K % 4 == 0 (KCONT) / rows % 4 == 0 (k-strided)): every
+// load is ONE unconditional global_load_dwordx4 from a clamped, always-valid address; out-of-range vectors are
+// zeroed on the data.  No branch, no per-load wait (cdna_hip_programming.md trap (c)).  Otherwise: guarded scalars.
+// Staged tile fragment of one thread: 16 scalars (plain registers; a float4[4] that is read "transposed" gets
+// parked in scratch by hipcc).  v[4*p + i] = i-th element of load p.
+struct Frag16 { float v[16]; };
+
+template <bool KCONT, bool VEC>
+__device__ __forceinline__ void g_load(Frag16& reg, const float* __restrict__ src, long ld, int row0, int k0,
+                                       int rows, int K) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        if (KCONT) {
-            const int r = row0 + (tid >> 3) + 32 * p, k = k0 + (tid & 7) * 4;
-            int cnt = (r < rows) ? min(4, K - k) : 0;
-            reg[p] = load4(src + (long)r * ld + k, cnt, vec);
+        int r, k;
+        if (KCONT) { r = row0 + (tid >> 3) + 32 * p; k = k0 + (tid & 7) * 4; }
+        else       { k = k0 + (tid >> 5) * 4 + p;    r = row0 + (tid & 31) * 4; }
+        if (VEC) {
+            const bool ok = r < rows && k < K;
+            const int rc = KCONT ? min(r, rows - 1) : min(r, rows - 4);
+            const int kc = KCONT ? min(k, K - 4) : min(k, K - 1);
+            const float* q = KCONT ? src + (long)rc * ld + kc : src + (long)kc * ld + rc;
+            const float4 t = ldg4(q);
+            reg.v[4 * p + 0] = ok ? t.x : 0.f; reg.v[4 * p + 1] = ok ? t.y : 0.f;
+            reg.v[4 * p + 2] = ok ? t.z : 0.f; reg.v[4 * p + 3] = ok ? t.w : 0.f;
         } else {
-            const int k = k0 + (tid >> 5) * 4 + p, r = row0 + (tid & 31) * 4;     // thread owns a 4(k) x 4(row) block
-            int cnt = (k < K) ? min(4, rows - r) : 0;
-            reg[p] = load4(src + (long)k * ld + r, cnt, vec);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = KCONT ? r : r + i, kk = KCONT ? k + i : k;
+                const bool ok = rr < rows && kk < K;
+                const float* q = KCONT ? src + (long)min(rr, rows - 1) * ld + min(kk, K - 1)
+                                       : src + (long)min(kk, K - 1) * ld + min(rr, rows - 1);
+                const float v = *q;
+                reg.v[4 * p + i] = ok ? v : 0.f;
+            }
         }
     }
 }
 
 template <bool KCONT, typename T, int LDS_LD>
-__device__ __forceinline__ void s_store(const float4 (&reg)[4], T* __restrict__ tile) {
+__device__ __forceinline__ void s_store(const Frag16& reg, T* __restrict__ tile) {
     const int tid = threadIdx.x;
+    if (KCONT) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (KCONT) {
+        for (int p = 0; p < 4; ++p) {
             const int r = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
-            typedef T T4 __attribute__((ext_vector_type(4)));
-            *(T4*)(tile + r * LDS_LD + k) = (T4){cvt<T>(reg[p].x), cvt<T>(reg[p].y), cvt<T>(reg[p].z), cvt<T>(reg[p].w)};
+            store4_ct(tile + r * LDS_LD + k, reg.v[4 * p], reg.v[4 * p + 1], reg.v[4 * p + 2], reg.v[4 * p + 3]);
         }
-    }
-    if (!KCONT) {
-        const int k = (tid >> 5) * 4, r = (tid & 31) * 4;
-        typedef T T4 __attribute__((ext_vector_type(4)));
-        *(T4*)(tile + (r + 0) * LDS_LD + k) = (T4){cvt<T>(reg[0].x), cvt<T>(reg[1].x), cvt<T>(reg[2].x), cvt<T>(reg[3].x)};
-        *(T4*)(tile + (r + 1) * LDS_LD + k) = (T4){cvt<T>(reg[0].y), cvt<T>(reg[1].y), cvt<T>(reg[2].y), cvt<T>(reg[3].y)};
-        *(T4*)(tile + (r + 2) * LDS_LD + k) = (T4){cvt<T>(reg[0].z), cvt<T>(reg[1].z), cvt<T>(reg[2].z), cvt<T>(reg[3].z)};
-        *(T4*)(tile + (r + 3) * LDS_LD + k) = (T4){cvt<T>(reg[0].w), cvt<T>(reg[1].w), cvt<T>(reg[2].w), cvt<T>(reg[3].w)};
+    } else {
+        const int k = (tid >> 5) * 4, r = (tid & 31) * 4;      // load p = k offset, element i = row offset
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            store4_ct(tile + (r + i) * LDS_LD + k, reg.v[i], reg.v[4 + i], reg.v[8 + i], reg.v[12 + i]);
     }
 }
 
-template <int PREC, bool A_KCONT, bool B_KCONT>
+template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                   long lda, long sA, const float* __restrict__ B, long ldb, long sB,
                                                   float beta, float* __restrict__ C, long ldc, long sC,
-                                                  const float* __restrict__ bias, int act, int vecA, int vecB,
-                                                  int ksplit) {
+                                                  const float* __restrict__ bias, int act, int ksplit) {
     typedef typename Elem<PREC>::T T;
     constexpr int LD = BK + Elem<PREC>::PAD;
-    __shared__ __attribute__((aligned(16))) T As[BM * LD];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) T As2[2][BM * LD];      // double buffered: one barrier per k-tile
+    __shared__ __attribute__((aligned(16))) T Bs2[2][BN * LD];
 
     // blockIdx.z = batch index, or (ksplit > 1, batch == 1) the K-slice whose partial product is added atomically
     const int bz = ksplit > 1 ? 0 : (int)blockIdx.z;
@@ -107,22 +108,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[4], rb[4];
+    Frag16 ra, rb;
     const int nk_all = (K + BK - 1) / BK;
     const int per = (nk_all + ksplit - 1) / ksplit;
     const int kt0 = ksplit > 1 ? (int)blockIdx.z * per : 0;
     const int nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
-    g_load<A_KCONT>(ra, A, lda, m0, kt0 * BK, M, K, vecA);
-    g_load<B_KCONT>(rb, B, ldb, n0, kt0 * BK, N, K, vecB);
+    g_load<A_KCONT, VEC>(ra, A, lda, m0, kt0 * BK, M, K);
+    g_load<B_KCONT, VEC>(rb, B, ldb, n0, kt0 * BK, N, K);
+    s_store<A_KCONT, T, LD>(ra, As2[0]);
+    s_store<B_KCONT, T, LD>(rb, Bs2[0]);
+    __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
-        __syncthreads();                       // previous tile's fragment reads are done
-        s_store<A_KCONT, T, LD>(ra, As);
-        s_store<B_KCONT, T, LD>(rb, Bs);
-        __syncthreads();
-        if (kt + 1 < nk) {                     // prefetch next k-tile into registers
-            g_load<A_KCONT>(ra, A, lda, m0, (kt + 1) * BK, M, K, vecA);
-            g_load<B_KCONT>(rb, B, ldb, n0, (kt + 1) * BK, N, K, vecB);
+        const int cur = (kt - kt0) & 1;
+        const T* As = As2[cur];
+        const T* Bs = Bs2[cur];
+        if (kt + 1 < nk) {                     // next k-tile: global -> registers, in flight across the MFMAs below
+            g_load<A_KCONT, VEC>(ra, A, lda, m0, (kt + 1) * BK, M, K);
+            g_load<B_KCONT, VEC>(rb, B, ldb, n0, (kt + 1) * BK, N, K);
         }
         if constexpr (PREC == LAS_PREC_BF16) {
             bf16x8 af[4], bfr[4];
@@ -154,6 +157,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
                     }
             }
         }
+        if (kt + 1 < nk) {                     // registers -> the other LDS buffer (nobody reads it this iteration)
+            s_store<A_KCONT, T, LD>(ra, As2[cur ^ 1]);
+            s_store<B_KCONT, T, LD>(rb, Bs2[cur ^ 1]);
+        }
+        __syncthreads();
     }
     // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -181,13 +189,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
     }
 }
 
-template <int PREC>
+template <int PREC, bool VEC>
 int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda,
            long sA, const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
-           int act, int vecA, int vecB, int ksplit) {
-#define LAS_GEMM_GO(AK, BK_)                                                                                     \
-    hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
-                       sB, beta, C, ldc, sC, bias, act, vecA, vecB, ksplit)
+           int act, int ksplit) {
+#define LAS_GEMM_GO(AK, BK_)                                                                                          \
+    hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_, VEC>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
+                       sB, beta, C, ldc, sC, bias, act, ksplit)
     if (!ta && tb) LAS_GEMM_GO(true, true);
     else if (!ta && !tb) LAS_GEMM_GO(true, false);
     else if (ta && !tb) LAS_GEMM_GO(false, false);
@@ -197,8 +205,6 @@ int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float
     return LAS_OK;
 }
 
-// out[n] = beta*out[n] + sum_m X[m,n]   (bias gradients).  grid (N/64, M-slices); slices meet through float atomics
-// after a tiny pre-pass has applied beta.
 // C[m][:] = beta * C[m][:]  (or 0)
 __global__ __launch_bounds__(256) void scale2d_kernel(float beta, int N, float* __restrict__ C, long ldc) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -250,19 +256,20 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
         if (ksplit > 64) ksplit = 64;
         if (ksplit < 1) ksplit = 1;
     }
-    const int vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (((uintptr_t)A & 15) == 0);
-    const int vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0);
+    // fast path: every operand vector is a whole, 16-byte aligned float4 inside the matrix
+    const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (((uintptr_t)A & 15) == 0) && (transA ? M % 4 == 0 : K % 4 == 0);
+    const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0) && (transB ? K % 4 == 0 : N % 4 == 0);
+    const bool vec = vecA && vecB && K >= 4 && M >= 4 && N >= 4;
     hipStream_t st = (hipStream_t)stream;
     if (ksplit > 1) {
         grid.z = ksplit;
         hipLaunchKernelGGL(scale2d_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, beta, N, C, (long)ldc);
         LAS_LAUNCH_OK();
     }
-    if (prec == LAS_PREC_BF16)
-        return launch<LAS_PREC_BF16>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta,
-                                     C, ldc, strideC, bias, act, vecA, vecB, ksplit);
-    return launch<LAS_PREC_F32>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C,
-                                ldc, strideC, bias, act, vecA, vecB, ksplit);
+#define LAS_GEMM_ARGS transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit
+    if (prec == LAS_PREC_BF16) return vec ? launch<LAS_PREC_BF16, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_BF16, false>(LAS_GEMM_ARGS);
+    return vec ? launch<LAS_PREC_F32, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_F32, false>(LAS_GEMM_ARGS);
+#undef LAS_GEMM_ARGS
 }
 
 extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {

@@ -91,11 +91,25 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 // ---------------------------------------------------------------- bf16 helpers
 typedef unsigned short bf16_t;
-__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even; NaN stays NaN
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// (MI355X_MICROARCH.md "Correctness boundaries").  Use the packed forms below where two or more values convert.
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+typedef __attribute__((ext_vector_type(2))) float las_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 las_bf16x2;
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {       // one v_cvt_pk_bf16_f32
+    const las_f32x2 v = {a, b};
+    const las_bf16x2 h = __builtin_convertvector(v, las_bf16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+// 4 converted values stored as one 8-byte (bf16) / 16-byte (f32) access
+__device__ __forceinline__ void store4_ct(unsigned short* dst, float a, float b, float c, float d) {
+    *(uint2*)dst = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+__device__ __forceinline__ void store4_ct(float* dst, float a, float b, float c, float d) {
+    *(float4*)dst = make_float4(a, b, c, d);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 

@@ -23,6 +23,7 @@
 //   * the published history doubles as the saved activations for BPTT.
 // Backward mirrors this with dgates[B,4H] as the exchanged quantity and W_hh^T columns resident.
 #include "las_mma.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -72,8 +73,7 @@ __device__ __forceinline__ void block_signal(unsigned* cnt) {
 }
 
 __device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
-    const unsigned v = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-    __hip_atomic_store((unsigned*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
     const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
@@ -107,6 +107,7 @@ __device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int row
 }
 
 struct LstmArgs {
+    int dbg;                  // timing experiments only (LAS_DBG_LSTM): 1 no wait, 2 no pull, 4 no MFMA, 8 no bwd-only stores
     int T, B, H, ND, U, G;
     int NS, Bs;               // batch slices (independent sub-recurrences) and rows per slice
     int sr, concat, T_out, F_out;
@@ -193,15 +194,15 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
                                   : make_float2(0.f, 0.f);
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
         if (s > 0) {
-            if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
+            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
         }
         __syncthreads();
         // (d) gate pre-activations: wave w <-> gate w
         f32x4 acc[NB];
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
+        if (s > 0 && !(a.dbg & 4)) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
         // (e) accumulators -> LDS  (C/D layout: col = lane&15 = unit, row = (lane>>4)*4 + r = batch)
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt)
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         }
         // (g) publish: only the exchange stores are outstanding here
         block_signal(cnt);
+        if (a.dbg & 8) continue;
 #pragma unroll
         for (int p = 0; p < PP; ++p) {
             if (!ev[p]) continue;
@@ -331,15 +333,15 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
             for (int c = 0; c < NC; ++c) {
                 if (c > 0) __syncthreads();               // previous chunk fully consumed
                 // rows have stride K4 in memory; this chunk = real columns [c*KC, c*KC + kreal)
-                pull_tile_sc1<T, VEC, 8>(src, Bl, min(KC, K4 - c * KC), K4, c * KC, Dl, ldc);
+                if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 8>(src, Bl, min(KC, K4 - c * KC), K4, c * KC, Dl, ldc);
                 __syncthreads();
                 // A = Dl rows (batch) x k ; B = Wl rows (unit) x k, offset to this chunk/wave quarter
-                mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);
+                if (!(a.dbg & 4)) mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);
             }
         }
 #pragma unroll
@@ -424,6 +426,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     else if (concat) { a.T_out = T / sr; a.F_out = sr * ND * H; }
     else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
     a.y_is_hf = 0;
+    { static const char* e = getenv("LAS_DBG_LSTM"); a.dbg = e ? atoi(e) : 0; }
 }
 
 template <int PREC, int NB>

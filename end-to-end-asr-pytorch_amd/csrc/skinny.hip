@@ -58,10 +58,7 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (row[u] >= 0) {
-                    typedef T T4 __attribute__((ext_vector_type(4)));
-                    *(T4*)(tile + row[u] * ld + dcol + col[u]) = (T4){to_ct<T>(v[u].x), to_ct<T>(v[u].y), to_ct<T>(v[u].z), to_ct<T>(v[u].w)};
-                }
+                if (row[u] >= 0) store4_ct(tile + row[u] * ld + dcol + col[u], v[u].x, v[u].y, v[u].z, v[u].w);
         }
     } else {
         const int total = nrows * n;
@@ -197,11 +194,9 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
     f32x4 acc[NB];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto pack = [](const float4& lo, const float4& hi) -> bf16x8 {
-        bf16x8 r;
-        r[0] = (short)f2bf(lo.x); r[1] = (short)f2bf(lo.y); r[2] = (short)f2bf(lo.z); r[3] = (short)f2bf(lo.w);
-        r[4] = (short)f2bf(hi.x); r[5] = (short)f2bf(hi.y); r[6] = (short)f2bf(hi.z); r[7] = (short)f2bf(hi.w);
-        return r;
+    auto pack = [](const float4& lo, const float4& hi) -> bf16x8 {       // 4 x v_cvt_pk_bf16_f32
+        const u32x4 r = {pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w)};
+        return __builtin_bit_cast(bf16x8, r);
     };
     // global k-step index over the concatenated segments; wave w takes k-steps w, w+DW, ...
     // Every load is unconditional from a clamped (always valid) address; out-of-range pieces are zeroed on the data.

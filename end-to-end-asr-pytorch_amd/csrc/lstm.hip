@@ -106,6 +106,31 @@ __device__ __forceinline__ void pull_tile_sc1(const T* __restrict__ src, int row
     }
 }
 
+// acc[bt] += A(tile rows, k) * Wfrag over KS k-steps with BOTH operands in registers: the A fragments come straight
+// from global memory (sc1 buffer loads of the tile other CUs just published), the B fragments (weights) were loaded
+// once at kernel start.  Lane (fr = lane&15, fq = lane>>4) holds k = 32*ks + 8*fq + {0..7} of row fr.
+// Out-of-range rows / columns read through the descriptor's bounds check (0, no branch).  bf16 only.
+template <int NB, int KS>
+__device__ __forceinline__ void mma_direct(f32x4 (&acc)[NB], const bf16_t* __restrict__ tile, int rows, int row_ld,
+                                           int col0, int cols, const bf16x8 (&wfrag)[KS]) {
+    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tile, 0, rows * row_ld * 2, 0x00020000);
+    u32x4 afr[NB][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const int r = bt * 16 + fr, c = ks * 32 + fq * 8;
+            const int off = (r < rows && c < cols) ? (r * row_ld + col0 + c) * 2 : 0x7ffffff0;
+            afr[bt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+            acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afr[bt][ks]), wfrag[ks], acc[bt], 0, 0, 0);
+}
+
 struct LstmArgs {
     int dbg;                  // timing experiments only (LAS_DBG_LSTM): 1 no wait, 2 no pull, 4 no MFMA, 8 no bwd-only stores
     int T, B, H, ND, U, G;
@@ -124,7 +149,7 @@ __device__ __forceinline__ long y_offset(const LstmArgs& a, int t, int b, int d,
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int PREC, int NB>
+template <int PREC, int NB, int KS>     // KS > 0: register-resident operands (bf16), KS k-steps per wave; 0: LDS path
 __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -155,6 +180,15 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) Hl[i] = (T)0;
     for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     __syncthreads();
+    // register-resident weight fragments of my gate (wave w <-> gate w), read back from the LDS tile once
+    bf16x8 wfrag[KS > 0 ? KS : 1];
+    if constexpr (KS > 0) {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wfrag[ks] = (ks * 32 < Kp) ? *(const bf16x8*)((const bf16_t*)Wl + (wave_ * 16 + (lane_ & 15)) * ld + ks * 32 + (lane_ >> 4) * 8)
+                                       : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
     // ---- my pointwise elements: pairs (b, n..n+1); eb = row within the slice
     constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
@@ -193,16 +227,31 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
                 xp[p][gi] = ev[p] ? *(const float2*)(xproj + ((long)t * B + b0 + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p])
                                   : make_float2(0.f, 0.f);
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
-        if (s > 0) {
-            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
-        }
-        __syncthreads();
-        // (d) gate pre-activations: wave w <-> gate w
         f32x4 acc[NB];
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0 && !(a.dbg & 4)) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
+        if (s > 0) {
+            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            // every wave needs the whole h tile: one shared pull into LDS (a direct global->register read per wave
+            // would fetch it four times through sc1 and measured slower)
+            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
+            __syncthreads();
+            // (d) gate pre-activations: wave w <-> gate w
+            if constexpr (KS > 0) {               // weights from registers, h from LDS
+                const int lane_ = threadIdx.x & 63;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if (ks * 32 < Kp) {
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) {
+                            const bf16x8 av = *(const bf16x8*)((const bf16_t*)Hl + (bt * 16 + (lane_ & 15)) * ld + ks * 32 + (lane_ >> 4) * 8);
+                            acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wfrag[ks], acc[bt], 0, 0, 0);
+                        }
+                    }
+            } else {
+                if (!(a.dbg & 4)) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
+            }
+        }
         // (e) accumulators -> LDS  (C/D layout: col = lane&15 = unit, row = (lane>>4)*4 + r = batch)
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt)
@@ -258,7 +307,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
 // ------------------------------------------------------------------------------------------------ backward
 // dh_rec[b][j] = sum_m dgates_next[b][m] * W_hh[m][j]; K = 4H is walked in NC chunks so the pulled
 // dgates tile fits in LDS for large H; wave w takes a quarter of each chunk's k-steps.
-template <int PREC, int NB>
+template <int PREC, int NB, int KS>     // KS > 0: register-resident operands (bf16, NC == 1), KS k-steps per wave
 __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4p, const float* __restrict__ dy,
                                                       const float* __restrict__ gates, const float* __restrict__ cs,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -287,6 +336,14 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     for (int i = threadIdx.x; i < NB * 16 * ldc; i += NT) Dl[i] = (T)0;
     for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     __syncthreads();
+    // register-resident W_hh^T fragments of my k-quarter (wave w <-> k-steps [w*KS, (w+1)*KS))
+    bf16x8 wfrag[KS > 0 ? KS : 1];
+    if constexpr (KS > 0) {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wfrag[ks] = *(const bf16x8*)((const bf16_t*)Wl + (lane_ & 15) * ldw + (wave_ * KS + ks) * 32 + (lane_ >> 4) * 8);
+    }
 
     constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
     const int half = U / 2;
@@ -335,6 +392,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
         if (s > 0) {
             if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
+            if constexpr (KS > 0) {
+                mma_direct<NB, KS>(acc, (const bf16_t*)src, Bl, K4, wave * KS * 32, K4 - wave * KS * 32, wfrag);
+            } else
             for (int c = 0; c < NC; ++c) {
                 if (c > 0) __syncthreads();               // previous chunk fully consumed
                 // rows have stride K4 in memory; this chunk = real columns [c*KC, c*KC + kreal)
@@ -429,22 +489,22 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     { static const char* e = getenv("LAS_DBG_LSTM"); a.dbg = e ? atoi(e) : 0; }
 }
 
-template <int PREC, int NB>
+template <int PREC, int NB, int KS>
 int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
                const float* w_hh, const int32_t* lens, float* y, float* hf, void* hx, float* gates, float* cs,
                SyncWords* sync, int* status) {
-    auto k = lstm_fwd_kernel<PREC, NB>;
+    auto k = lstm_fwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (typename CT<PREC>::T*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }
-template <int PREC, int NB>
+template <int PREC, int NB, int KS>
 int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, const float* dy, const float* gates,
                const float* cs, const float* w_hh, const int32_t* lens, void* dgx, float* dgf, SyncWords* sync,
                int* status) {
-    auto k = lstm_bwd_kernel<PREC, NB>;
+    auto k = lstm_bwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
                        (typename CT<PREC>::T*)dgx, dgf, sync, status);
@@ -485,11 +545,19 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+#define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
-        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_>(a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status)));
-    } else if (prec == LAS_PREC_F32) {
-        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_F32, NB_>(a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status)));
+        // register-resident operands for the common hidden sizes and small batch slices (VGPR budget: KS*4*(1+NB))
+        const int ksteps = ((H + 31) / 32);
+        const bool direct = NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT");
+        if (direct && ksteps <= 8)  { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
+        if (direct && ksteps <= 10) { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
+        if (direct && ksteps <= 16 && NB == 1) { return launch_fwd<LAS_PREC_BF16, 1, 16>(LAS_FWD_ARGS); }
+        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_, 0>(LAS_FWD_ARGS)));
+    } else {
+        LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_F32, NB_, 0>(LAS_FWD_ARGS)));
     }
+#undef LAS_FWD_ARGS
     return LAS_E_BADARG;
 }
 
@@ -513,10 +581,17 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+#define LAS_BWD_ARGS a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
-        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_>(a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status)));
-    } else if (prec == LAS_PREC_F32) {
-        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_F32, NB_>(a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status)));
+        const int kq = K4p / 32 / 4;                        // k-steps per wave
+        const bool direct = NB <= 2 && NC == 1 && !getenv("LAS_LSTM_NO_DIRECT");
+        if (direct && kq == 8)  { LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_BWD_ARGS))); }
+        if (direct && kq == 10) { LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_BWD_ARGS))); }
+        if (direct && kq == 16 && NB == 1) { return launch_bwd<LAS_PREC_BF16, 1, 16>(LAS_BWD_ARGS); }
+        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_, 0>(LAS_BWD_ARGS)));
+    } else {
+        LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_F32, NB_, 0>(LAS_BWD_ARGS)));
     }
+#undef LAS_BWD_ARGS
     return LAS_E_BADARG;
 }

@@ -75,6 +75,25 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
                        f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
 
 
+PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_kernel', 'gemm': 'gemm_kernel<0, true, true'}
+
+
+def attach_pmc_traffic(roof, workload):
+    """`traffic` = HBM bytes per launch of the group's dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    The profiler cannot run inside the bench, so the figure comes from profiles/r01_pmc_traffic_<workload>.json."""
+    path = os.path.join(ROOT, 'profiles', f'r01_pmc_traffic_{workload}.json')
+    if not os.path.exists(path):
+        return
+    pmc = json.load(open(path))
+    for row in [roof] + roof.get('breakdown', []):
+        key = next((v for k, v in PMC_KEYS.items() if row.get('kernel', '').startswith(k)), None)
+        hit = next((v for n, v in pmc.items() if key and key in n), None)
+        if hit:
+            row['traffic'] = hit['hbm_MB_per_launch_corrected'] * 1e6
+            row['traffic_unit'] = 'B/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)'
+
+
 def note(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -160,6 +179,7 @@ def main():
     torch.cuda.synchronize()
     roof = ops.kernel_timing_summary(prof)
     ops.disable_kernel_timing()
+    attach_pmc_traffic(roof, a.workload)
 
     if rank == 0:
         out = {

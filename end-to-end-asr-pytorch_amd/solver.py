@@ -63,7 +63,7 @@ class Solver:
         if not (getattr(paras, 'gpu', True) and torch.cuda.is_available()):
             raise ops._lib.LasError('this build has no CPU path: a HIP device is required (the reference CPU path is '
                                     'restated only as the test oracle under oracle/)')
-        self.device = torch.device('cuda', self.local_rank)
+        self.device = torch.device('cuda', self.local_rank % torch.cuda.device_count())
         torch.cuda.set_device(self.device)
         self.exp_name = paras.name
         if self.exp_name is None:

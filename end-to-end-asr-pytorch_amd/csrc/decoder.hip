@@ -11,6 +11,7 @@
 //           LSTM cells                         skinny MFMA product, cell epilogue
 // Everything needed by the backward pass is kept in caller-owned buffers (las_dec_state).
 #include "las_mma.h"
+#include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
                       long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
@@ -52,15 +53,19 @@ struct AttArgs {
     float* e;                 // [B][Tp]
     float* f;                 // [B][10][Tp]  (loc, saved)
     float* s;                 // [B][Tp][A]   (loc, saved)
+    int dbg;                  // timing experiments only (LAS_DBG_ATTF): 1 skip main loop, 2 skip conv, 4 skip fills, 8 return
 };
 
 // grid (NCH, B): energies of T'-chunk [t0, t0+TC) of utterance b
-template <bool LOC>
+constexpr int ATT_ROWS = 5;     // rows of a T'-chunk per wave: chunks are <= 20 frames (att_chunks), 4 waves
+
+template <bool LOC, int AI>     // AI = ceil(A / 64) rounded up to {1,2,4,5,8}
 __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.y, t0 = blockIdx.x * a.TC, len = a.lens[b];
     const int t1 = min(t0 + a.TC, a.Tp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.dbg & 8) return;
     float* q_l = sm;                                 // [A]
     fill_batched<2>(a.q + (long)b * a.A, a.A, [&](int i, float v) { q_l[i] = v; });
     if (!LOC) {
@@ -81,9 +86,11 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
     float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
     float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]
+    if (!(a.dbg & 4)) {
     fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
     fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
     fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+    }
     {
         const float* __restrict__ pr = a.prev + (long)b * a.Tp;
         for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
@@ -94,45 +101,53 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     }
     __syncthreads();
     // location features f[c][t] = sum_k w[c][k] * prev[t + k - K]
-    for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
+    for (int i = threadIdx.x; i < ((a.dbg & 2) ? 0 : LOC_C * a.TC); i += 256) {
         const int c = i / a.TC, tt = i % a.TC;
         float acc = 0.f;
         if (t0 + tt < t1) {
             const float* w = cw_l + c * LOC_W;
             const float* p = prev_l + tt;
-#pragma unroll 3
-            for (int k = 0; k < LOC_W; ++k) acc += w[k] * p[k];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;             // 3 chains x unroll: LDS latency, not issue, bounds this loop
+#pragma unroll 8
+            for (int k = 0; k + 2 < LOC_W; k += 3) { a0 += w[k] * p[k]; a1 += w[k + 1] * p[k + 1]; a2 += w[k + 2] * p[k + 2]; }
+            acc = (a0 + a1) + a2;                           // LOC_W = 201 = 3 * 67
             a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] = acc;
         }
         f_l[c * a.TC + tt] = acc;
     }
     __syncthreads();
     const float be = a.b_e[0];
-    for (int t = t0 + wave; t < t1; t += 4) {
+    // every psi row this wave will touch is requested before the first one is used (one memory round trip)
+    float pv[ATT_ROWS][AI];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
+        const float* __restrict__ p = a.psi + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+        for (int k = 0; k < AI; ++k) pv[r][k] = p[min(lane + 64 * k, a.A - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int t = t0 + wave + 4 * r;
+        if (t >= t1 || (a.dbg & 1)) break;
         float acc = 0.f;
         const int tt = t - t0;
         if (t < len) {
-            const float* __restrict__ p = a.psi + ((long)b * a.Tp + t) * a.A;
             float* __restrict__ so = a.s + ((long)b * a.Tp + t) * a.A;
             float fc[LOC_C];
 #pragma unroll
             for (int c = 0; c < LOC_C; ++c) fc[c] = f_l[c * a.TC + tt];
-            for (int i0 = lane; i0 < a.A; i0 += 256) {          // 4 independent psi loads in flight per lane
-                float pv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pv[k] = p[min(i0 + 64 * k, a.A - 1)];     // unconditional, clamped
+            for (int k = 0; k < AI; ++k) {
+                const int i = lane + 64 * k;
+                if (i < a.A) {
+                    float u = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = i0 + 64 * k;
-                    if (i < a.A) {
-                        float u = 0.f;
-#pragma unroll
-                        for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
-                        u = fast_tanh(u);
-                        const float sv = fast_tanh(pv[k] + q_l[i] + u);
-                        so[i] = sv;
-                        acc += we_l[i] * sv;
-                    }
+                    for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
+                    u = fast_tanh(u);
+                    const float sv = fast_tanh(pv[r][k] + q_l[i] + u);
+                    so[i] = sv;
+                    acc += we_l[i] * sv;
                 }
             }
             acc = wave_sum(acc) + be;
@@ -222,7 +237,9 @@ __global__ __launch_bounds__(256) void pick_token_kernel(const float* __restrict
     (void)red;
 }
 
-int att_chunks(int Tp) { int n = (Tp + 19) / 20; return n < 1 ? 1 : (n > 32 ? 32 : n); }
+// T' is cut into chunks of <= 20 frames: a wave of the energy kernels then owns <= 5 rows (ATT_ROWS) and can request
+// all of them up front.  Must be identical in decoder.hip and decoder_bwd.hip.
+int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 
 }  // namespace
 
@@ -255,6 +272,7 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
         LAS_LAUNCH_OK();
     }
     const int NCH = att_chunks(Tp), TC = (Tp + NCH - 1) / NCH, ECH = (E + 63) / 64;
+    if (TC > 20) return LAS_E_UNSUPPORTED;
     size_t lds_e = sizeof(float) * (size_t)A;
     if (loc) lds_e = sizeof(float) * ((size_t)2 * A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + LOC_C * TC);
     if (lds_e > 64 * 1024) return LAS_E_UNSUPPORTED;
@@ -274,8 +292,17 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
         a.e = s.ebuf;
         a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
         a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
-        if (loc) hipLaunchKernelGGL(att_energy_fwd<true>, dim3(NCH, B), dim3(256), lds_e, st, a);
-        else hipLaunchKernelGGL(att_energy_fwd<false>, dim3(NCH, B), dim3(256), lds_e, st, a);
+        { static const char* e = getenv("LAS_DBG_ATTF"); a.dbg = e ? atoi(e) : 0; }
+        if (!loc) hipLaunchKernelGGL((att_energy_fwd<false, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
+        else {
+            const int AI = (A + 63) / 64;
+            if (AI <= 1) hipLaunchKernelGGL((att_energy_fwd<true, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            else if (AI <= 2) hipLaunchKernelGGL((att_energy_fwd<true, 2>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            else if (AI <= 4) hipLaunchKernelGGL((att_energy_fwd<true, 4>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            else if (AI <= 5) hipLaunchKernelGGL((att_energy_fwd<true, 5>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            else if (AI <= 8) hipLaunchKernelGGL((att_energy_fwd<true, 8>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            else return LAS_E_UNSUPPORTED;
+        }
         LAS_LAUNCH_OK();
         float* xin_t = s.xin + (long)t * B * XI;
         hipLaunchKernelGGL(att_softmax_ctx, dim3(ECH, B), dim3(256), lds_s, st, Tp, E, s.ebuf, enc, enc_len,

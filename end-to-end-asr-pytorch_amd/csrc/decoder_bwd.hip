@@ -186,22 +186,32 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
     }
     float dbe = 0.f;
-    for (int tt = wave; tt < ((a.dbg & 1) ? 0 : tcv); tt += 4) {
+    // all rows this wave touches (<= ATT_ROWS, chunks are <= 20 frames) are requested up front: one round trip
+    constexpr int ATT_ROWS = 5;
+    float svr[ATT_ROWS][AI], dpr[ATT_ROWS][AI];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
+        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
+        const float* __restrict__ dpp = a.dpsi + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+        for (int k = 0; k < AI; ++k) {
+            const int i = min(lane + 64 * k, a.A - 1);
+            svr[r][k] = sp[i];
+            dpr[r][k] = dpp[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int tt = wave + 4 * r;
+        if (tt >= tcv || (a.dbg & 1)) break;
         const int t = t0 + tt;
         const float de = de_l[tt];
         dbe += de;
         float fc[LOC_C], dfc[LOC_C];
 #pragma unroll
         for (int c = 0; c < LOC_C; ++c) { fc[c] = f_l[c * a.TC + tt]; dfc[c] = 0.f; }
-        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
         float* __restrict__ dp = a.dpsi + ((long)b * a.Tp + t) * a.A;
-        float sv[AI], dpv[AI];                       // all loads of the row first (independent, in flight together)
-#pragma unroll
-        for (int k = 0; k < AI; ++k) {
-            const int i = lane + 64 * k;
-            sv[k] = sp[min(i, a.A - 1)];           // unconditional, clamped; masked where used
-            dpv[k] = dp[min(i, a.A - 1)];
-        }
 #pragma unroll
         for (int k = 0; k < AI; ++k) {
             const int i = lane + 64 * k;
@@ -210,10 +220,11 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
                 u = fast_tanh(u);
-                const float dz = de * we_l[i] * (1.f - sv[k] * sv[k]);
+                const float sv = svr[r][k];
+                const float dz = de * we_l[i] * (1.f - sv * sv);
                 dq_r[k] += dz;
-                dp[i] = dpv[k] + dz;
-                dwe_r[k] += de * sv[k];
+                dp[i] = dpr[r][k] + dz;
+                dwe_r[k] += de * sv;
                 const float du = dz * (1.f - u * u);
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) { dwlp_r[k][c] += du * fc[c]; dfc[c] += du * wlp_l[c * a.A + i]; }
@@ -283,7 +294,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&demb[(long)tk * C + i], dx[(long)r * ldx + i]);
 }
 
-int att_chunks(int Tp) { int n = (Tp + 19) / 20; return n < 1 ? 1 : (n > 32 ? 32 : n); }
+// T' is cut into chunks of <= 20 frames: a wave of the energy kernels then owns <= 5 rows (ATT_ROWS) and can request
+// all of them up front.  Must be identical in decoder.hip and decoder_bwd.hip.
+int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 
 }  // namespace
 

@@ -29,15 +29,32 @@
 static inline size_t las_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ---------------------------------------------------------------- wave / block reductions
+// Wave-wide reductions on DPP (plain VALU ops).  __shfl_xor compiles to ds_bpermute_b32: an LDS-crossbar round trip per
+// step, six dependent ones per reduction -- measured as the dominant cost of kernels doing ten reductions per row.
+// row_shr:1,2,4,8 leave each 16-lane row's total in its lane 15; row_bcast:15 / :31 fold the rows; lane 63 has the
+// wave total, which is broadcast with v_readlane.  Lanes without a DPP source receive `keep`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float las_dpp(float keep, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += las_dpp<0x111, 0xf>(0.f, v);
+    v += las_dpp<0x112, 0xf>(0.f, v);
+    v += las_dpp<0x114, 0xf>(0.f, v);
+    v += las_dpp<0x118, 0xf>(0.f, v);
+    v += las_dpp<0x142, 0xa>(0.f, v);
+    v += las_dpp<0x143, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, las_dpp<0x111, 0xf>(v, v));
+    v = fmaxf(v, las_dpp<0x112, 0xf>(v, v));
+    v = fmaxf(v, las_dpp<0x114, 0xf>(v, v));
+    v = fmaxf(v, las_dpp<0x118, 0xf>(v, v));
+    v = fmaxf(v, las_dpp<0x142, 0xa>(v, v));
+    v = fmaxf(v, las_dpp<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // Block-wide reductions; `red` is >= 32 floats of LDS; every thread gets the result.
 __device__ __forceinline__ float block_sum(float v, float* red) {

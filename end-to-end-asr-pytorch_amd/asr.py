@@ -159,10 +159,10 @@ class Seq2Seq(nn.Module):
             obj = getattr(obj, q)
         return obj
 
-    def _cat(self, prefix, kind, shape):
-        """Kernel-facing view over the adjacent per-direction parameters (no copy)."""
+    def _cat(self, prefix, kind, shape, grads=False):
+        """Kernel-facing view over the adjacent per-direction parameters (or their gradients), no copy."""
         off, k, _ = self.param_slices[f'{prefix}.{kind}_l0']
-        return self.flat_params[off:off + k * self.ND].view(shape)
+        return (self.flat_grads if grads else self.flat_params)[off:off + k * self.ND].view(shape)
 
     def init_parameters(self):
         """Same scheme as reference asr.py:114-153 (LeCun normal; decoder forget-gate bias_ih = 1; embed N(0,1))."""
@@ -206,7 +206,9 @@ class Seq2Seq(nn.Module):
                     leaves.append(self.P(f'{pre}.{kind}_l0{s}'))
             cats = (self._cat(pre, 'weight_ih', (self.ND * 4 * H, I_)), self._cat(pre, 'weight_hh', (self.ND, 4 * H, H)),
                     self._cat(pre, 'bias_ih', (self.ND * 4 * H,)), self._cat(pre, 'bias_hh', (self.ND * 4 * H,)))
-            h = ops.lstm_layer_leaves(h, lens_dev, cats, sr, self.concat, self.status, self.ND, leaves)
+            cat_grads = (self._cat(pre, 'weight_ih', (self.ND * 4 * H, I_), True), self._cat(pre, 'weight_hh', (self.ND, 4 * H, H), True),
+                         self._cat(pre, 'bias_ih', (self.ND * 4 * H,), True), self._cat(pre, 'bias_hh', (self.ND * 4 * H,), True))
+            h = ops.lstm_layer_leaves(h, lens_dev, cats, sr, self.concat, self.status, self.ND, leaves, cat_grads)
             if sr > 1:
                 lens_host = [int(v / sr) for v in lens_host]              # asr.py:497
                 lens_dev = torch.div(lens_dev, sr, rounding_mode='floor').to(torch.int32)

@@ -169,21 +169,36 @@ class DecoderFn(torch.autograd.Function):
         with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (2 * A + E) * (2 if loc else 1), 'byte'):
             check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
                                      ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
-        # ---- contractions over the L steps: one GEMM each
+        # ---- contractions over the L steps: one GEMM each; the weight gradients are off the dependency chain and go
+        # to the side stream, accumulated into the flat gradient buffer when every parameter offers one
         LB = L * B
         XI = C + E
         g = {}
         g['embed.weight'] = Bw['demb']
         hs0_prev = S['hs'][0, :L].reshape(LB, C)
-        g['attention.phi.weight'] = ops.gemm(Bw['dq_pre'].view(LB, A), hs0_prev, transA=True)
-        for l in range(NL):
-            dg = Bw['dgates'][l].view(LB, 4 * C)
-            x_l = S['xin'].view(LB, XI) if l == 0 else S['hs'][l - 1, 1:].reshape(LB, C)
-            g[f'decoder.layer{l}.weight_ih'] = ops.gemm(dg, x_l, transA=True)
-            g[f'decoder.layer{l}.weight_hh'] = ops.gemm(dg, S['hs'][l, :L].reshape(LB, C), transA=True)
-            gb = ops.colsum(dg, torch.empty(4 * C, **f32))
-            g[f'decoder.layer{l}.bias_ih'] = gb
-            g[f'decoder.layer{l}.bias_hh'] = gb.clone()
+        tg = {n: ops.wgrad_target(W[n]) for n in names}
+        direct = all(tg[n] is not None for n in names if n not in ('embed.weight', 'char_trans.weight', 'char_trans.bias'))
+
+        def dec_wgrads(out, beta):
+            ops.gemm(Bw['dq_pre'].view(LB, A), hs0_prev, out['attention.phi.weight'], transA=True, beta=beta)
+            for l in range(NL):
+                dg = Bw['dgates'][l].view(LB, 4 * C)
+                x_l = S['xin'].view(LB, XI) if l == 0 else S['hs'][l - 1, 1:].reshape(LB, C)
+                ops.gemm(dg, x_l, out[f'decoder.layer{l}.weight_ih'], transA=True, beta=beta)
+                ops.gemm(dg, S['hs'][l, :L].reshape(LB, C), out[f'decoder.layer{l}.weight_hh'], transA=True, beta=beta)
+                ops.colsum(dg, out[f'decoder.layer{l}.bias_ih'], beta=beta)
+                ops.colsum(dg, out[f'decoder.layer{l}.bias_hh'], beta=beta)
+
+        if direct:
+            ops.on_side_stream(lambda: dec_wgrads(tg, 1.0), [Bw['dq_pre'], Bw['dgates'], S['xin'], S['hs']])
+        else:
+            g['attention.phi.weight'] = torch.empty(A, C, **f32)
+            for l in range(NL):
+                g[f'decoder.layer{l}.weight_ih'] = torch.empty(4 * C, XI if l == 0 else C, **f32)
+                g[f'decoder.layer{l}.weight_hh'] = torch.empty(4 * C, C, **f32)
+                g[f'decoder.layer{l}.bias_ih'] = torch.empty(4 * C, **f32)
+                g[f'decoder.layer{l}.bias_hh'] = torch.empty(4 * C, **f32)
+            dec_wgrads(g, 0.0)
         # d enc[b] [T',E] = att[:,b]^T [T' x L] * dctx[:,b] [L x E]
         att = S['att'][1:]
         d_enc = torch.empty(B, Tp, E, **f32)

@@ -69,6 +69,55 @@ def kernel_timing_summary(records):
     return top
 
 
+# ----------------------------------------------------------------------------- side stream for weight gradients
+# Weight-gradient GEMMs are off the backward dependency chain, and the persistent LSTM kernels that follow them
+# occupy only ND*ceil(H/16)*slices CUs: run the wgrads on a second HIP stream, accumulating directly into the
+# flat gradient buffer (param.grad views), and join before the optimiser.
+_SIDE = {'enabled': True, 'stream': None, 'dirty': False}
+
+
+def set_wgrad_overlap(flag):
+    _SIDE['enabled'] = bool(flag)
+
+
+def _side_stream():
+    if _SIDE['stream'] is None:
+        _SIDE['stream'] = torch.cuda.Stream()
+    return _SIDE['stream']
+
+
+def wgrad_target(p):
+    """The buffer a weight gradient may be accumulated into directly (leaf with a preallocated .grad), else None."""
+    if _SIDE['enabled'] and p is not None and p.is_leaf and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
+def on_side_stream(fn, inputs):
+    """Run fn() on the side stream after everything enqueued so far on the current stream; `inputs` are tensors fn
+    reads (kept alive for the side stream through record_stream)."""
+    main = torch.cuda.current_stream()
+    side = _side_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    _SIDE['dirty'] = True
+
+
+def join_side_stream():
+    """Make the current stream wait for all side-stream work (call before reading gradients)."""
+    if _SIDE['dirty']:
+        ev = torch.cuda.Event()
+        ev.record(_SIDE['stream'])
+        torch.cuda.current_stream().wait_event(ev)
+        _SIDE['dirty'] = False
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -242,7 +291,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.view(-1, x.shape[-1])
         y = gemm(x2, w, transB=True, bias=b, act=act)
         ctx.save_for_backward(x2, w, y if act else None)
-        ctx.act, ctx.has_b, ctx.xshape = act, b is not None, x.shape
+        ctx.act, ctx.has_b, ctx.xshape, ctx.bias = act, b is not None, x.shape, b
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -254,6 +303,15 @@ class LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = gemm(gy, w).view(ctx.xshape)                       # [M,N]x[N,K]
+        b = ctx.bias
+        tw, tb = wgrad_target(w), (wgrad_target(b) if b is not None else None)
+        if ctx.needs_input_grad[1] and tw is not None and (not ctx.has_b or tb is not None):
+            def side():
+                gemm(gy, x2, tw, transA=True, beta=1.0)             # accumulate into the flat gradient buffer
+                if ctx.has_b:
+                    colsum(gy, tb, beta=1.0)
+            on_side_stream(side, [gy, x2])
+            return gx, None, None, None
         if ctx.needs_input_grad[1]:
             gw = gemm(gy, x2, transA=True)                          # [N,M]x[M,K]
         if ctx.has_b and ctx.needs_input_grad[2]:
@@ -297,8 +355,10 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
     return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec)
 
 
-def _lstm_bwd(saved, gy, need_gx):
-    """-> gx [T,B,I]|None, gw_ih [ND*4H,I], gw_hh [ND,4H,H], gb [ND*4H] (= d b_ih = d b_hh)."""
+def _lstm_bwd(saved, gy, need_gx, targets=None):
+    """-> gx [T,B,I]|None, gw_ih [ND*4H,I], gw_hh [ND,4H,H], gb [ND*4H] (= d b_ih = d b_hh).
+    targets = (gw_ih, gw_hh, gb_ih, gb_hh) gradient buffers to accumulate into on the side stream (returns None
+    for the weight gradients then)."""
     L_ = _lib.lib()
     x, lens, w_ih, w_hh, hf, gates, cs, status, sr, concat, prec = saved
     T, B, Iin = x.shape
@@ -314,20 +374,32 @@ def _lstm_bwd(saved, gy, need_gx):
                                   I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
               'las_lstm_rec_bwd')
     x2 = x.view(T * B, Iin)
-    gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
-    gw_ih = gemm(dgf, x2, transA=True)                                         # [ND*4H, I]
-    gb = colsum(dgf, torch.empty(ND * H4, dtype=torch.float32, device=dev))
-    gw_hh = torch.empty_like(w_hh)
     hf2 = hf.view(T * B, ND * H)
-    for d in range(ND):
-        if T > 1:
-            if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
-                A, Bm = dgf[B:, d * H4:(d + 1) * H4], hf2[:(T - 1) * B, d * H:(d + 1) * H]
-            else:           # sum_{t<=T-2} dg[t]^T h[t+1]
-                A, Bm = dgf[:(T - 1) * B, d * H4:(d + 1) * H4], hf2[B:, d * H:(d + 1) * H]
-            gemm(A, Bm, gw_hh[d], transA=True)
-        else:
-            gw_hh[d].zero_()
+
+    def wgrads(gw_ih, gw_hh, gb_ih, gb_hh, beta):
+        gemm(dgf, x2, gw_ih, transA=True, beta=beta)                            # [ND*4H, I]
+        colsum(dgf, gb_ih, beta=beta)
+        if gb_hh is not None:
+            colsum(dgf, gb_hh, beta=beta)
+        for d in range(ND):
+            if T > 1:
+                if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
+                    A, Bm = dgf[B:, d * H4:(d + 1) * H4], hf2[:(T - 1) * B, d * H:(d + 1) * H]
+                else:           # sum_{t<=T-2} dg[t]^T h[t+1]
+                    A, Bm = dgf[:(T - 1) * B, d * H4:(d + 1) * H4], hf2[B:, d * H:(d + 1) * H]
+                gemm(A, Bm, gw_hh[d], transA=True, beta=beta)
+            elif beta == 0.0:
+                gw_hh[d].zero_()
+
+    if targets is not None:
+        on_side_stream(lambda: wgrads(targets[0], targets[1], targets[2], targets[3], 1.0), [dgf, x, hf])
+        gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
+        return gx, None, None, None
+    gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
+    gw_ih = torch.empty(ND * H4, Iin, dtype=torch.float32, device=dev)
+    gw_hh = torch.empty_like(w_hh)
+    gb = torch.empty(ND * H4, dtype=torch.float32, device=dev)
+    wgrads(gw_ih, gw_hh, gb, None, 0.0)
     return gx, gw_ih, gw_hh, gb
 
 
@@ -357,17 +429,21 @@ class _LstmLeavesFn(torch.autograd.Function):
     leaves order: for kind in (w_ih, w_hh, b_ih, b_hh): for direction."""
 
     @staticmethod
-    def forward(ctx, x, lens, sr, concat, status, cats, *leaves):
+    def forward(ctx, x, lens, sr, concat, status, cats, cat_grads, *leaves):
         w_ih, w_hh, b_ih, b_hh = cats
         y, ctx.saved = _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status)
         ctx.shapes = [tuple(l.shape) for l in leaves]
+        ctx.cat_grads = cat_grads if _SIDE['enabled'] else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        gx, gw_ih, gw_hh, gb = _lstm_bwd(ctx.saved, gy, ctx.needs_input_grad[0])
+        gx, gw_ih, gw_hh, gb = _lstm_bwd(ctx.saved, gy, ctx.needs_input_grad[0], ctx.cat_grads)
         ND = ctx.saved[3].shape[0]
+        n_leaves = len(ctx.shapes)
         ctx.saved = None
+        if gw_ih is None:                   # accumulated into the flat gradient buffer on the side stream
+            return (gx, None, None, None, None, None, None, *([None] * n_leaves))
         out = []
         k = 0
         for g in (gw_ih, gw_hh, gb, gb):
@@ -375,11 +451,11 @@ class _LstmLeavesFn(torch.autograd.Function):
             for d in range(ND):
                 out.append(flat[d].view(ctx.shapes[k]))
                 k += 1
-        return (gx, None, None, None, None, None, *out)
+        return (gx, None, None, None, None, None, None, *out)
 
 
-def lstm_layer_leaves(x, lens, cats, sr, concat, status, ND, leaves):
-    return _LstmLeavesFn.apply(x, lens, sr, concat, status, cats, *leaves)
+def lstm_layer_leaves(x, lens, cats, sr, concat, status, ND, leaves, cat_grads=None):
+    return _LstmLeavesFn.apply(x, lens, sr, concat, status, cats, cat_grads, *leaves)
 
 
 # ----------------------------------------------------------------------------- joint loss

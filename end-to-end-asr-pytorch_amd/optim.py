@@ -31,6 +31,8 @@ class FlatOptimizer:
 
     def step(self, zero_grad=True):
         """Clip + update; leaves (norm, coef, skip) in self.norm3 on the device."""
+        from . import ops
+        ops.join_side_stream()             # weight gradients may still be accumulating on the side stream
         L_ = _lib.lib()
         n = self.p.numel()
         check(L_.las_grad_norm(ptr(self.g), LL(n), F(1.0 / self.world_size), F(GRAD_CLIP), ptr(self.ws), ptr(self.norm3),

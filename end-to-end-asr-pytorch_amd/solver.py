@@ -153,6 +153,7 @@ class Trainer(Solver):
         loss, att_loss, ctc_loss = ops.joint_loss(att_pred, ctc_pred, y, ntok, self.asr_model.last_enc_len_dev, ans_len,
                                                   self.ctc_weight)
         loss.backward()                                           # solver.py:177
+        ops.join_side_stream()                                    # weight-gradient GEMMs ran on the side stream
         ldist.allreduce_grads(self.asr_model.flat_grads)
         self.asr_opt.step(zero_grad=True)                         # clip 5, NaN guard, update (solver.py:178-182)
         return loss, att_loss, ctc_loss, att_pred, ans_len

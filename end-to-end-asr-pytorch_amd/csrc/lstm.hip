@@ -58,9 +58,15 @@ __device__ __forceinline__ bool wait_counter(unsigned* cnt, unsigned target, uns
     return true;
 }
 
-// Block-wide wait: lane 0 polls, result broadcast through LDS word `flag`.
+// The thread that polls and signals: lane 0 of the LAST wave.  A wave's vector-memory results return in issue order,
+// and with <= 16-row batch slices the pointwise work (and with it the cold x-projection prefetch and the
+// backward-only stores) lives in waves 0-1; the last wave's queue holds nothing but its share of the pull, so its
+// poll is never stuck behind a cold HBM access.
+#define LAS_SYNC_THREAD (NT - 64)
+
+// Block-wide wait: one lane polls, result broadcast through LDS word `flag`.
 __device__ __forceinline__ bool block_wait(unsigned* cnt, unsigned target, unsigned* abort_word, int* flag) {
-    if (threadIdx.x == 0) *flag = wait_counter(cnt, target, abort_word) ? 1 : 0;
+    if (threadIdx.x == LAS_SYNC_THREAD) *flag = wait_counter(cnt, target, abort_word) ? 1 : 0;
     __syncthreads();
     return *flag != 0;
 }
@@ -69,7 +75,7 @@ __device__ __forceinline__ bool block_wait(unsigned* cnt, unsigned target, unsig
 __device__ __forceinline__ void block_signal(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == LAS_SYNC_THREAD) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {

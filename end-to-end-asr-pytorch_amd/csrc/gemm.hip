@@ -67,6 +67,18 @@ __device__ __forceinline__ void g_load(Frag16& reg, const float* __restrict__ sr
     }
 }
 
+// Interior tiles (all 128 rows and all 32 k inside the matrix, aligned): base pointer precomputed once per thread,
+// four unconditional 16-byte loads, no clamping, no masking -- the generic loader above spends more VALU issue
+// slots on address arithmetic and selects than the tile's 16 MFMAs take.
+template <bool KCONT>
+__device__ __forceinline__ void g_load_fast(Frag16& reg, const float* __restrict__ base, long ld, int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float4 t = KCONT ? ldg4(base + (long)(32 * p) * ld + k0) : ldg4(base + (long)(k0 + p) * ld);
+        reg.v[4 * p + 0] = t.x; reg.v[4 * p + 1] = t.y; reg.v[4 * p + 2] = t.z; reg.v[4 * p + 3] = t.w;
+    }
+}
+
 template <bool KCONT, typename T, int LDS_LD>
 __device__ __forceinline__ void s_store(const Frag16& reg, T* __restrict__ tile) {
     const int tid = threadIdx.x;
@@ -109,13 +121,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     Frag16 ra, rb;
+    const bool a_full = VEC && (m0 + BM <= M), b_full = VEC && (n0 + BN <= N);
+    const float* a_base = A_KCONT ? A + (long)(m0 + (threadIdx.x >> 3)) * lda + (threadIdx.x & 7) * 4
+                                  : A + (long)((threadIdx.x >> 5) * 4) * lda + m0 + (threadIdx.x & 31) * 4;
+    const float* b_base = B_KCONT ? B + (long)(n0 + (threadIdx.x >> 3)) * ldb + (threadIdx.x & 7) * 4
+                                  : B + (long)((threadIdx.x >> 5) * 4) * ldb + n0 + (threadIdx.x & 31) * 4;
     const int nk_all = (K + BK - 1) / BK;
     const int per = (nk_all + ksplit - 1) / ksplit;
     const int kt0 = ksplit > 1 ? (int)blockIdx.z * per : 0;
     const int nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
-    g_load<A_KCONT, VEC>(ra, A, lda, m0, kt0 * BK, M, K);
-    g_load<B_KCONT, VEC>(rb, B, ldb, n0, kt0 * BK, N, K);
+    {
+        const bool k_full = (kt0 + 1) * BK <= K;
+        if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, kt0 * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, kt0 * BK, M, K);
+        if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, kt0 * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, kt0 * BK, N, K);
+    }
     s_store<A_KCONT, T, LD>(ra, As2[0]);
     s_store<B_KCONT, T, LD>(rb, Bs2[0]);
     __syncthreads();
@@ -124,8 +144,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         const T* As = As2[cur];
         const T* Bs = Bs2[cur];
         if (kt + 1 < nk) {                     // next k-tile: global -> registers, in flight across the MFMAs below
-            g_load<A_KCONT, VEC>(ra, A, lda, m0, (kt + 1) * BK, M, K);
-            g_load<B_KCONT, VEC>(rb, B, ldb, n0, (kt + 1) * BK, N, K);
+            const bool k_full = (kt + 2) * BK <= K;
+            if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, (kt + 1) * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, (kt + 1) * BK, M, K);
+            if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, (kt + 1) * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, (kt + 1) * BK, N, K);
         }
         if constexpr (PREC == LAS_PREC_BF16) {
             bf16x8 af[4], bfr[4];

@@ -5,8 +5,7 @@ Attention and Speller, so checkpoints and the Trainer code carry over; every ten
 All parameters (and their gradients) are views of one flat fp32 buffer each, which the fused optimiser and the
 RCCL gradient all-reduce treat as a single vector.
 
-Not built here (out of scope / next rows): VGGExtractor front-end (N1), beam_decode + CTC prefix
-scorer (N3), multi-head attention (broken in the reference, asr.py:436), GRU cells, dropout > 0.
+Not built here (out of scope / next rows): beam_decode + CTC prefix scorer (N3), multi-head attention (broken in the reference, asr.py:436), GRU cells, dropout > 0.
 """
 import math
 import random
@@ -16,6 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .decoder import DecoderFn, weight_names
+from . import vgg as _vgg
 
 
 class FlatParams:
@@ -73,8 +73,7 @@ class Seq2Seq(nn.Module):
         super().__init__()
         device = torch.device(device if device is not None else 'cuda')
         enc, att, dec = model_para['encoder'], model_para.get('attention'), model_para.get('decoder')
-        if 'VGG' in enc['enc_type']:
-            raise NotImplementedError('VGGExtractor front-end is not built yet (SURVEY.md §8f N1)')
+        self.vgg = 'VGG' in enc['enc_type']
         if enc['rnn_cell'].upper() != 'LSTM':
             raise NotImplementedError('only LSTM encoder cells are built')
         self.dims = [int(v) for v in str(enc['dim']).split('_')]
@@ -96,6 +95,11 @@ class Seq2Seq(nn.Module):
         in_dim = int(example_input.shape[-1])
 
         fp = FlatParams()
+        if self.vgg:                                                    # Listener.__init__, asr.py:285-288
+            cin, _, in_dim = _vgg.check_dim(in_dim)
+            for i, (co, ci) in enumerate(((64, cin), (64, 64), (128, 64), (128, 128)), 1):
+                fp.add(f'encoder.vgg_extractor.conv{i}.weight', co, ci, 3, 3)
+                fp.add(f'encoder.vgg_extractor.conv{i}.bias', co)
         self.enc_in = []
         sfx = ['', '_reverse'] if self.bidir else ['']
         for l, (H, sr) in enumerate(zip(self.dims, self.srs)):
@@ -191,9 +195,14 @@ class Seq2Seq(nn.Module):
     # -- encoder ---------------------------------------------------------------------------------------------
     def encode(self, x, lens_dev, lens_host):
         """Listener.forward, reference asr.py:311-317; x [B,T,D] batch-major -> enc [B,T',E], enc_len (host list)."""
-        h = ops.Transpose01Fn.apply(x)                     # time-major from here on
         lens_dev = lens_dev.clone()
         lens_host = list(lens_host)
+        if self.vgg:                                       # asr.py:312-313; time-major from here on
+            h = _vgg.VGGFn.apply(x, True, *[self.P('encoder.vgg_extractor.' + n) for n in _vgg.NAMES])
+            lens_host = [v // 4 for v in lens_host]        # view_input, asr.py:535
+            lens_dev = torch.div(lens_dev, 4, rounding_mode='floor').to(torch.int32)
+        else:
+            h = ops.Transpose01Fn.apply(x)
         for l, (H, sr) in enumerate(zip(self.dims, self.srs)):
             pre = f'encoder.layer{l}.layer'
             I_ = self.enc_in[l]
@@ -232,7 +241,7 @@ class Seq2Seq(nn.Module):
             lens_host = [int(v) for v in state_len]
             lens_dev = torch.tensor(lens_host, dtype=torch.int32, device=x.device)
         T = max(lens_host)                                   # pad_packed_sequence trims to the longest (asr.py:483)
-        if T < x.shape[1]:
+        if T < x.shape[1] and not self.vgg:                  # the VGG front-end convolves over the padding too
             x = x[:, :T].contiguous()
         enc, enc_len_dev, enc_len = self.encode(x.float(), lens_dev, lens_host)
         ctc_output = att_output = att_maps = None

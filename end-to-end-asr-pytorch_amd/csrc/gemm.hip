@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
                 float v = alpha * acc[i][j][r] + bv;
                 if (beta != 0.f) v += beta * (*c);
                 if (act == LAS_ACT_TANH) v = tanhf(v);
+                else if (act == LAS_ACT_RELU) v = v < 0.f ? 0.f : v;
                 *c = v;
             }
         }

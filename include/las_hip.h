@@ -22,7 +22,7 @@ extern "C" {
 #define LAS_ABI_VERSION 1
 enum { LAS_OK = 0, LAS_E_BADARG = -1, LAS_E_UNSUPPORTED = -2, LAS_E_WORKSPACE = -3, LAS_E_TIMEOUT = -4 };
 enum { LAS_PREC_BF16 = 0, LAS_PREC_F32 = 1 };
-enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1 };
+enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1, LAS_ACT_RELU = 2 };
 
 int las_abi_version(void);
 const char* las_error_string(int code);
@@ -43,7 +43,7 @@ int las_ctc_loss_bwd(const float* logits, const int32_t* label, const int32_t* e
                      const float* gscale, float* grad_logits, void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- GEMM with fused epilogue --------------------------------------------------------------
- * C[M,N] = alpha*opA(A)*opB(B) + beta*C + bias[N], then optional tanh.  Row-major; opA(A) is MxK:
+ * C[M,N] = alpha*opA(A)*opB(B) + beta*C + bias[N], then optional tanh / ReLU.  Row-major; opA(A) is MxK:
  * transA=0 -> A stored [M,K] (lda>=K), transA=1 -> A stored [K,M] (lda>=M); opB(B) is KxN:
  * transB=0 -> B stored [K,N], transB=1 -> B stored [N,K] (an nn.Linear weight).  `batch` strided
  * instances (strides in elements).  Replaces nn.Linear at src/asr.py:307,316 (proj+tanh), :46,69
@@ -206,6 +206,38 @@ int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, floa
  * mean over utterances (np.argmax + cal_acc at src/postprocess.py:121-133, called every step at solver.py:187) */
 int las_argmax_rows(const float* logits, int rows, int V, int32_t* pred, void* stream);
 int las_token_acc(const int32_t* pred, const int64_t* y, int Ly, int B, int L, float* out, void* stream);
+
+/* ---- VGG front-end of the Listener -----------------------------------------------------------
+ * Replaces VGGExtractor.forward (src/asr.py:546-558; view_input :533-544, check_dim :522-531) and its autograd
+ * backward: x [B][T][D] (D = C_in*F, delta channel outermost; F = 13 if D%13==0 else 40 if D%40==0) ->
+ * conv3x3(C_in->64)+ReLU, conv3x3(64->64)+ReLU, MaxPool2d(2), conv3x3(64->128)+ReLU, conv3x3(128->128)+ReLU,
+ * MaxPool2d(2) -> out [B][T/4][128*(F/4)] (time_major=0) or [T/4][B][128*(F/4)] (time_major=1), feature index
+ * c*(F/4)+f as the reference's transpose+view.  The T%4 tail frames are dropped; lengths are the caller's (//4).
+ * Activations are kept channels-last [B][T][F][C]; all buffers are caller-owned (sizes from las_vgg_get_dims):
+ *   y1,y2 [R1][64]  p1 [R2][64]  y3,y4 [R2][128]  idx1 [R2][64] bytes  idx2 [R3][128] bytes
+ *   col [col_floats] scratch (3x3 patch matrix of one convolution, refilled per convolution)
+ *   wr [wr_floats] weights re-ordered to [C_out][tap][C_in] (written by fwd, read by bwd)
+ *   dwr [wr_floats], ga, gb [R1][64]   (bwd only)
+ * w[i] [C_out][C_in][3][3] and b[i] [C_out] are the reference's conv{1..4}.weight/bias; bwd ACCUMULATES into
+ * dw[i]/db[i] and, when dx != NULL, writes dx [B][T][D] (zero in the dropped tail). */
+typedef struct {
+    int C_in, F, Tt, T2, F2, T4, F4, out_dim;   /* Tt = T - T%4, T2 = Tt/2, F2 = F/2, T4 = T2/2, F4 = F2/2 */
+    int Kp[4];                                   /* patch-row length of conv i: 9*C_in(i) rounded up to 32 */
+    int64_t R1, R2, R3;                          /* B*Tt*F, B*T2*F2, B*T4*F4 */
+    int64_t col_floats, wr_floats;
+} las_vgg_dims;
+typedef struct { const float* w[4]; const float* b[4]; } las_vgg_params;
+typedef struct { float* dw[4]; float* db[4]; } las_vgg_grads;
+typedef struct {
+    float *y1, *y2, *p1, *y3, *y4;
+    uint8_t *idx1, *idx2;
+    float *col, *wr, *dwr, *ga, *gb;
+} las_vgg_state;
+int las_vgg_get_dims(int B, int T, int D, las_vgg_dims* dims);
+int las_vgg_fwd(int prec, const float* x, int B, int T, int D, const las_vgg_params* params, las_vgg_state* state,
+                float* out, int time_major, void* stream);
+int las_vgg_bwd(int prec, const float* x, const float* dout, int B, int T, int D, int time_major,
+                const las_vgg_state* state, const las_vgg_grads* grads, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

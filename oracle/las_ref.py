@@ -11,6 +11,7 @@ Reference lines restated (all under /root/reference):
   infer_lengths      src/solver.py:134-136
   lstm_dir / bilstm  src/asr.py:466-501   (nn.LSTM packed semantics; gate order i,f,g,o)
   listener           src/asr.py:266-317   (RNNLayer -> tanh(Linear) per layer)
+  vgg_extractor      src/asr.py:507-558   (4x conv3x3+ReLU, 2x MaxPool2d(2); time /4, freq /4)
   attention_*        src/asr.py:370-462   (dot / loc, softmax scale 2.0, mask -inf)
   speller_step       src/asr.py:320-357
   seq2seq_forward    src/asr.py:58-112
@@ -43,7 +44,7 @@ def parse_cfg(model_para):
     bidir = 'Bi' in enc['enc_type']
     style = enc['sample_style']
     ctc_w = float(model_para['optimizer']['joint_ctc'])
-    return dict(dims=dims, srs=srs, bidir=bidir, style=style, ctc_w=ctc_w,
+    return dict(dims=dims, srs=srs, bidir=bidir, style=style, ctc_w=ctc_w, vgg='VGG' in enc['enc_type'],
                 att_mode=model_para['attention']['att_mode'].lower(),
                 dec_layers=int(model_para['decoder']['layer']), dec_dim=int(model_para['decoder']['dim']))
 
@@ -122,8 +123,60 @@ def rnn_layer(x, lens, W, prefix, sr, style, bidir, fast=False):
     return y, list(lens)
 
 
+def vgg_dims(d):
+    """check_dim, asr.py:522-531: (in_channel, freq_dim, out_dim)."""
+    if d % 13 == 0:
+        return d // 13, 13, (13 // 4) * 128
+    if d % 40 == 0:
+        return d // 40, 40, (40 // 4) * 128
+    raise ValueError('Acoustic feature dimension for VGG should be 13/26/39(MFCC) or 40/80/120(Fbank) but got %d' % d)
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _ConvBf16Operands(torch.autograd.Function):
+    """conv3x3(pad 1) whose matrix-product operands are rounded to bf16 (RNE) with fp32 accumulation, forward and
+    backward: the arithmetic of the product's bf16 mode.  Used only to check that mode tightly: with the reference's
+    pure-fp32 arithmetic the ReLU masks / max-pool winners of near-ties differ, which moves whole gradient terms."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(_rb(x), _rb(w), b, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = torch.nn.grad.conv2d_input(x.shape, _rb(w), _rb(g), padding=1)
+        gw = torch.nn.grad.conv2d_weight(_rb(x), w.shape, _rb(g), padding=1)
+        return gx, gw, g.sum((0, 2, 3))
+
+
+def vgg_extractor(x, lens, W, prefix='encoder.vgg_extractor', bf16_operands=False):
+    """asr.py:533-558.  x (B,T,D) -> (B, T//4, 128*(F//4)); lengths //4; the T%4 tail frames are dropped."""
+    conv = _ConvBf16Operands.apply if bf16_operands else (lambda h, w, b: F.conv2d(h, w, b, padding=1))
+    B, T, D = x.shape
+    cin, fd, od = vgg_dims(D)
+    lens = [v // 4 for v in lens]
+    if T % 4:
+        x = x[:, :T - T % 4]
+    h = x.reshape(B, x.shape[1], cin, fd).transpose(1, 2)
+    h = F.relu(conv(h, W[f'{prefix}.conv1.weight'], W[f'{prefix}.conv1.bias']))
+    h = F.relu(conv(h, W[f'{prefix}.conv2.weight'], W[f'{prefix}.conv2.bias']))
+    h = F.max_pool2d(h, 2, stride=2)
+    h = F.relu(conv(h, W[f'{prefix}.conv3.weight'], W[f'{prefix}.conv3.bias']))
+    h = F.relu(conv(h, W[f'{prefix}.conv4.weight'], W[f'{prefix}.conv4.bias']))
+    h = F.max_pool2d(h, 2, stride=2)
+    h = h.transpose(1, 2)
+    return h.reshape(B, h.shape[1], od), lens
+
+
 def listener(x, lens, W, cfg, fast=False):
     """asr.py:311-317."""
+    if cfg.get('vgg'):
+        x, lens = vgg_extractor(x, lens, W)
     for l, (sr, _) in enumerate(zip(cfg['srs'], cfg['dims'])):
         x, lens = rnn_layer(x, lens, W, f'encoder.layer{l}', sr, cfg['style'], cfg['bidir'], fast)
         x = torch.tanh(F.linear(x, W[f'encoder.proj{l}.weight'], W[f'encoder.proj{l}.bias']))

@@ -40,7 +40,14 @@ def test_config_surface_errors():
     bad = dict(cfg, encoder=dict(cfg['encoder'], dim='256_256'))
     with pytest.raises(AssertionError):
         asr.param_shapes(torch.zeros(1, 10, 39), 63, bad)
-    bad = dict(cfg, encoder=dict(cfg['encoder'], enc_type='VGGBiRNN'))
+    vgg = dict(cfg, encoder=dict(cfg['encoder'], enc_type='VGGBiRNN'))
+    sh = asr.param_shapes(torch.zeros(1, 10, 39), 63, vgg)              # 3x13 MFCC -> 3 input channels, 3*128 features
+    assert sh['encoder.vgg_extractor.conv1.weight'] == (64, 3, 3, 3)
+    assert sh['encoder.vgg_extractor.conv4.weight'] == (128, 128, 3, 3)
+    assert sh['encoder.layer0.layer.weight_ih_l0'][1] == 384
+    with pytest.raises(ValueError):                                     # check_dim, asr.py:522-531
+        asr.param_shapes(torch.zeros(1, 10, 41), 63, vgg)
+    bad = dict(cfg, encoder=dict(cfg['encoder'], rnn_cell='GRU'))
     with pytest.raises(NotImplementedError):
         asr.param_shapes(torch.zeros(1, 10, 39), 63, bad)
     bad = dict(cfg, attention=dict(cfg['attention'], att_mode='foo'))

@@ -56,6 +56,21 @@ def test_listener():
         close(v.grad, d['grad.' + k[len('encoder.'):]])
 
 
+@pytest.mark.parametrize('name', ['mfcc26', 'fbank40'])
+def test_vgg(name):
+    """VGGExtractor (asr.py:507-558), incl. the dropped T%4 tail and floor pooling of odd freq dims."""
+    d = G(f'g1_vgg_{name}.npz')
+    W = {('V.' + k): v.requires_grad_(True) for k, v in W_of(d).items()}
+    x = torch.tensor(d['x'], requires_grad=True)
+    y, ol = R.vgg_extractor(x, list(d['lens']), W, prefix='V')
+    close(y, d['y'])
+    assert ol == list(d['out_lens'])
+    (y * torch.tensor(d['gy'])).sum().backward()
+    close(x.grad, d['gx'])
+    for k, v in W.items():
+        close(v.grad, d['grad.' + k[2:]], atol=5e-5)
+
+
 @pytest.mark.parametrize('mode', ['dot', 'loc'])
 def test_attention(mode):
     d = G(f'g1_attention_{mode}.npz')
@@ -136,7 +151,7 @@ def test_ctc_lattice(name, impl):
 
 
 @pytest.mark.parametrize('fast', [False, True])
-@pytest.mark.parametrize('name', ['dot_att', 'loc_ctc', 'ctc_only'])
+@pytest.mark.parametrize('name', ['dot_att', 'loc_ctc', 'ctc_only', 'vgg_loc_ctc'])
 def test_train_step(name, fast):
     """Whole step: forward, joint loss, backward, clip, 3 optimiser steps (Adam / Adadelta)."""
     import sys

@@ -24,7 +24,7 @@ def las():
 
 
 @pytest.mark.parametrize('prec', ['f32', 'bf16'])
-@pytest.mark.parametrize('name', ['dot_att', 'loc_ctc', 'ctc_only'])
+@pytest.mark.parametrize('name', ['dot_att', 'loc_ctc', 'ctc_only', 'vgg_loc_ctc'])
 def test_step_vs_reference(las, name, prec):
     ops, asr = las
     from gen_golden import TINY

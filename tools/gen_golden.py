@@ -142,6 +142,23 @@ def g1_listener(asr, out):
     np.savez(os.path.join(out, 'g1_listener.npz'), **d)
 
 
+def g1_vgg(asr, out):
+    """VGGExtractor (asr.py:507-558): MFCC-style 2x13 and fbank-style 1x40 inputs, T not a multiple of 4."""
+    for name, B, T, D in [('mfcc26', 2, 11, 26), ('fbank40', 2, 9, 40)]:
+        _seed(15)
+        gen = torch.Generator().manual_seed(10)
+        lens = [T, T - 3]
+        x = _ragged_x(B, T, D, lens, gen).requires_grad_(True)
+        vgg = asr.VGGExtractor(x)
+        y, olen = vgg(x, lens)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        d = {'x': _np(x), 'lens': np.array(lens), 'y': _np(y), 'out_lens': np.array(olen), 'gy': _np(gy), 'gx': _np(x.grad)}
+        d.update(_state(vgg, 'w.'))
+        d.update(_grads(vgg))
+        np.savez(os.path.join(out, f'g1_vgg_{name}.npz'), **d)
+
+
 def g1_attention(asr, out):
     for mode in ['dot', 'loc']:
         _seed(13)
@@ -236,6 +253,11 @@ TINY = {
                      dropout='0_0', rnn_cell='LSTM'),
         attention=dict(att_mode='loc', dim=6, proj=True, num_head=1),
         decoder=dict(dim=8, layer=2, dropout=0.0, rnn_cell='LSTMCell')),
+    'vgg_loc_ctc': dict(     # the structure of the shipped config/libri_example.yaml, tiny
+        optimizer=dict(type='Adadelta', learning_rate=1.0, joint_ctc=0.5),
+        encoder=dict(enc_type='VGGBiRNN', sample_rate='1_1', sample_style='drop', dim='8_8', dropout='0_0', rnn_cell='LSTM'),
+        attention=dict(att_mode='loc', dim=6, proj=True, num_head=1),
+        decoder=dict(dim=8, layer=1, dropout=0.0, rnn_cell='LSTMCell')),
     'ctc_only': dict(
         optimizer=dict(type='Adam', learning_rate=0.001, joint_ctc=1.0),
         encoder=dict(enc_type='BiRNN', sample_rate='2_1', sample_style='concat', dim='8_8',
@@ -308,7 +330,10 @@ def g3_steps(asr, out):
         _seed(31)
         gen = torch.Generator().manual_seed(9)
         V = 9
-        x, y, lens = _synth_batch(4, 17, 5, V, 4, gen)
+        if 'VGG' in cfg['encoder']['enc_type']:
+            x, y, lens = _synth_batch(3, 38, 26, V, 3, gen)        # D=26 = 2 x 13 MFCC-style; T'=9 after the 4x reduction
+        else:
+            x, y, lens = _synth_batch(4, 17, 5, V, 4, gen)
         rec = ref_step(asr, cfg, x, y, V, n_opt_steps=3)
         rec.update({'x': _np(x), 'y': _np(y), 'lens': np.array(lens), 'V': np.array(V)})
         np.savez(os.path.join(out, f'g3_step_{name}.npz'), **rec)
@@ -415,6 +440,7 @@ def main():
     g1_rnnlayer(asr, out)
     g1_listener(asr, out)
     g1_attention(asr, out)
+    g1_vgg(asr, out)
     g1_speller(asr, out)
     g2_ctc(out)
     g3_steps(asr, out)

@@ -33,13 +33,22 @@ WORKLOADS = {
     'c4': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
                enc=('320_320_320_320_320', '2_2_1_1_1'), att=('loc', 300), dec=320,
                name='LibriSpeech-360h subword (V=5000) LAS+CTC, bf16'),
+    # the reference's shipped config/libri_example.yaml, verbatim: VGG front-end + 5x320 BiLSTM (no pyramid), loc-attn, CTC 0.5
+    'c5': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+               enc=('320_320_320_320_320', '1_1_1_1_1'), enc_type='VGGBiRNN', style='drop', att=('loc', 300), dec=320,
+               name='config/libri_example.yaml: VGGBiRNN (VGG front-end + 5x320 BiLSTM), loc-attn, CTC 0.5, V=5000, bf16'),
 }
+
+
+def time_reduction(w):
+    synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
+    return synth.total_downsample(w['enc'][1]) * (4 if 'VGG' in w.get('enc_type', '') else 1)
 
 
 def model_cfg(w):
     nl = len(w['enc'][0].split('_'))
     return dict(optimizer=dict(type=w['opt'][0], learning_rate=w['opt'][1], joint_ctc=w['ctc']),
-                encoder=dict(enc_type='BiRNN', sample_rate=w['enc'][1], sample_style='concat', dim=w['enc'][0],
+                encoder=dict(enc_type=w.get('enc_type', 'BiRNN'), sample_rate=w['enc'][1], sample_style=w.get('style', 'concat'), dim=w['enc'][0],
                              dropout='_'.join(['0'] * nl), rnn_cell='LSTM'),
                 attention=dict(att_mode=w['att'][0], dim=w['att'][1], proj=True, num_head=1),
                 decoder=dict(dim=w['dec'], layer=1, dropout=0, rnn_cell='LSTMCell'))
@@ -49,7 +58,7 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
     """The oracle (torch-CPU restatement of the reference step, packed-LSTM fast path) on a bounded sample."""
     from oracle import las_ref as R
     synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
-    tr = synth.total_downsample(w['enc'][1])
+    tr = time_reduction(w)
     x, y, lens = synth.make_batch(0, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr)
     x, y, lens = x[:sample_B], y[:sample_B], lens[:sample_B]
     torch.manual_seed(0)
@@ -117,7 +126,7 @@ def main():
     world, rank, local = ldist.init()
     assert world == a.gpus or world == 1, (world, a.gpus)
     tmp = tempfile.mkdtemp(prefix='las_bench_')
-    tr = synth.total_downsample(w['enc'][1])
+    tr = time_reduction(w)
     config = dict(asr_model=cfg, clm=dict(enable=False),
                   solver=dict(dataset='synthetic', data_path='', n_jobs=0, max_timestep=0, max_label_len=0,
                               train_set=['train'], batch_size=w['B'], apex=False, total_steps=10 ** 9, tf_start=1.0,

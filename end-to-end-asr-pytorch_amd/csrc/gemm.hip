@@ -12,89 +12,11 @@
 // ds_read_b128 hit distinct banks); k-strided ("transposed") sources are read coalesced along rows and
 // scattered into that layout.  Register prefetch of the next k-tile overlaps the MFMAs of the current one.
 #include "las_common.h"
+#include "gemm_tile.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-
-template <int PREC> struct Elem;
-template <> struct Elem<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int PAD = 8; };   // 16 B
-template <> struct Elem<LAS_PREC_F32>  { typedef float  T; static constexpr int PAD = 4; };   // 16 B
-
-template <typename T> __device__ __forceinline__ T cvt(float f);
-template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float f) { return f2bf(f); }
-template <> __device__ __forceinline__ float cvt<float>(float f) { return f; }
-
-// Stage-in registers for one operand tile (128 rows x 32 k): 4 float4 per thread.
-// KCONT: element (r,k) at src[r*ld + k]; thread -> row = tid/8 + 32*p, k4 = (tid%8)*4.
-// else : element (r,k) at src[k*ld + r]; thread -> k = 4*(tid/32) + p, r4 = (tid%32)*4: a 4x4 block that is
-//        transposed in registers so the LDS writes are 4 consecutive k per row (8/16-byte stores).
-// VEC (host-checked: 16-B aligned base, ld % 4 == 0, and K % 4 == 0 (KCONT) / rows % 4 == 0 (k-strided)): every
-// load is ONE unconditional global_load_dwordx4 from a clamped, always-valid address; out-of-range vectors are
-// zeroed on the data.  No branch, no per-load wait (cdna_hip_programming.md trap (c)).  Otherwise: guarded scalars.
-// Staged tile fragment of one thread: 16 scalars (plain registers; a float4[4] that is read "transposed" gets
-// parked in scratch by hipcc).  v[4*p + i] = i-th element of load p.
-struct Frag16 { float v[16]; };
-
-template <bool KCONT, bool VEC>
-__device__ __forceinline__ void g_load(Frag16& reg, const float* __restrict__ src, long ld, int row0, int k0,
-                                       int rows, int K) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int r, k;
-        if (KCONT) { r = row0 + (tid >> 3) + 32 * p; k = k0 + (tid & 7) * 4; }
-        else       { k = k0 + (tid >> 5) * 4 + p;    r = row0 + (tid & 31) * 4; }
-        if (VEC) {
-            const bool ok = r < rows && k < K;
-            const int rc = KCONT ? min(r, rows - 1) : min(r, rows - 4);
-            const int kc = KCONT ? min(k, K - 4) : min(k, K - 1);
-            const float* q = KCONT ? src + (long)rc * ld + kc : src + (long)kc * ld + rc;
-            const float4 t = ldg4(q);
-            reg.v[4 * p + 0] = ok ? t.x : 0.f; reg.v[4 * p + 1] = ok ? t.y : 0.f;
-            reg.v[4 * p + 2] = ok ? t.z : 0.f; reg.v[4 * p + 3] = ok ? t.w : 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rr = KCONT ? r : r + i, kk = KCONT ? k + i : k;
-                const bool ok = rr < rows && kk < K;
-                const float* q = KCONT ? src + (long)min(rr, rows - 1) * ld + min(kk, K - 1)
-                                       : src + (long)min(kk, K - 1) * ld + min(rr, rows - 1);
-                const float v = *q;
-                reg.v[4 * p + i] = ok ? v : 0.f;
-            }
-        }
-    }
-}
-
-// Interior tiles (all 128 rows and all 32 k inside the matrix, aligned): base pointer precomputed once per thread,
-// four unconditional 16-byte loads, no clamping, no masking -- the generic loader above spends more VALU issue
-// slots on address arithmetic and selects than the tile's 16 MFMAs take.
-template <bool KCONT>
-__device__ __forceinline__ void g_load_fast(Frag16& reg, const float* __restrict__ base, long ld, int k0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float4 t = KCONT ? ldg4(base + (long)(32 * p) * ld + k0) : ldg4(base + (long)(k0 + p) * ld);
-        reg.v[4 * p + 0] = t.x; reg.v[4 * p + 1] = t.y; reg.v[4 * p + 2] = t.z; reg.v[4 * p + 3] = t.w;
-    }
-}
-
-template <bool KCONT, typename T, int LDS_LD>
-__device__ __forceinline__ void s_store(const Frag16& reg, T* __restrict__ tile) {
-    const int tid = threadIdx.x;
-    if (KCONT) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int r = (tid >> 3) + 32 * p, k = (tid & 7) * 4;
-            store4_ct(tile + r * LDS_LD + k, reg.v[4 * p], reg.v[4 * p + 1], reg.v[4 * p + 2], reg.v[4 * p + 3]);
-        }
-    } else {
-        const int k = (tid >> 5) * 4, r = (tid & 31) * 4;      // load p = k offset, element i = row offset
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            store4_ct(tile + (r + i) * LDS_LD + k, reg.v[i], reg.v[4 + i], reg.v[8 + i], reg.v[12 + i]);
-    }
-}
+using namespace las_tile;
 
 template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,

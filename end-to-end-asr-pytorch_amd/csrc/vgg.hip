@@ -2,14 +2,15 @@
 // MaxPool2d(2), conv3x3(64->128)+ReLU, conv3x3(128->128)+ReLU, MaxPool2d(2), and the whole backward.
 //
 // Layout: activations are channels-last [B][T][F][C] (one (b,t,f) "pixel" = one GEMM row), so a 3x3 tap of a pixel is
-// C contiguous floats and a convolution is  patches[R, 9C] x Wr[C_out, 9C]^T  on the MFMA GEMM with the bias+ReLU
-// epilogue (gemm.hip).  Wr is the reference's [C_out][C_in][3][3] weight re-ordered to [C_out][tap][C_in] once per
-// call.  The patch matrix lives in one scratch buffer that forward and backward re-fill per convolution (backward
-// recomputes it instead of keeping 4 of them).  Backward per convolution: db = colsum(dY), dWr = dY^T x patches
-// (split-K GEMM), dpatches = dY x Wr into the same scratch, then a gather (each input pixel sums its 9 taps) fused
-// with the ReLU mask of the layer below.  Max-pool keeps a 2-bit argmax per output (first maximum in (t,f) scan
-// order, as ATen) and its backward is a gather fused with the ReLU mask as well.
+// C contiguous floats.  conv2..4 (C_in = 64/128) run as implicit GEMMs (conv.hip): forward with the bias+ReLU
+// epilogue, the data gradient as the same kernel on dY with tap-flipped transposed weights and the ReLU mask of the
+// layer below as epilogue, the weight gradient as a pixel-split TN product with a gathered operand.  Weights are
+// re-ordered once per call from the reference's [C_out][C_in][3][3] to [C_out][tap][C_in] (and [C_in][8-tap][C_out]).
+// conv1 (C_in = 1..3, K = 9*C_in <= 27) is too thin for a gathered k-slab: its 32-wide zero-padded patch matrix is
+// materialised (R1 x 32 floats) and multiplied on the plain GEMM.  Max-pool keeps a 2-bit argmax per output (first
+// maximum in (t,f) scan order, as ATen); its backward is a gather fused with the ReLU mask.
 #include "las_common.h"
+#include "conv.h"
 
 namespace {
 
@@ -145,6 +146,15 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     wr[i] = tap < 9 ? w[((long)co * C + c) * 9 + tap] : 0.f;
 }
 
+// Wt[c][(8-tap)*Co + co] = w[co][c][tap]   (operand of the data-gradient convolution)
+__global__ __launch_bounds__(256) void pack_weight_flipped_kernel(const float* __restrict__ w, int Co, int C,
+                                                                  float* __restrict__ wt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Co * C * 9) return;
+    const int co = i % Co, tp = (i / Co) % 9, c = i / (9 * Co);
+    wt[i] = w[((long)co * C + c) * 9 + (8 - tp)];
+}
+
 // gw[co][c][tap] += dWr[co][tap*C + c]
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dwr, int Co, int C, int Kp,
                                                            float* __restrict__ gw) {
@@ -189,7 +199,7 @@ struct Geo {
     las_vgg_dims d;
     int cin[4], cout[4], T[4], F[4];
     long rows[4];
-    long wr_off[4];
+    long wr_off[4], wt_off[4];
 };
 
 int geometry(int B, int T, int D, Geo* g) {
@@ -207,6 +217,11 @@ int geometry(int B, int T, int D, Geo* g) {
         g->wr_off[i] = off;
         off += (long)cout[i] * d.Kp[i];
     }
+    for (int i = 1; i < 4; ++i) {
+        g->wt_off[i] = off;
+        off += (long)cin[i] * 9 * cout[i];
+    }
+    g->wt_off[0] = -1;
     return LAS_OK;
 }
 
@@ -228,10 +243,9 @@ extern "C" int las_vgg_get_dims(int B, int T, int D, las_vgg_dims* d) {
     int64_t wr = 0, col = 0;
     for (int i = 0; i < 4; ++i) {
         d->Kp[i] = (9 * cin[i] + 31) / 32 * 32;
-        wr += (int64_t)(i < 2 ? C1 : C2) * d->Kp[i];
-        const int64_t c = (i < 2 ? d->R1 : d->R2) * d->Kp[i];
-        if (c > col) col = c;
+        wr += (int64_t)(i < 2 ? C1 : C2) * d->Kp[i] * (i == 0 ? 1 : 2);      // + the flipped copy of conv2..4
     }
+    col = d->R1 * d->Kp[0];                                                   // only conv1 materialises patches
     d->wr_floats = wr;
     d->col_floats = col;
     return LAS_OK;
@@ -252,15 +266,25 @@ extern "C" int las_vgg_fwd(int prec, const float* x, int B, int T, int D, const 
         hipLaunchKernelGGL(pack_weight_kernel, dim3(nblk((long)g.cout[i] * d.Kp[i])), dim3(256), 0, st, p->w[i],
                            g.cout[i], g.cin[i], d.Kp[i], s->wr + g.wr_off[i]);
         LAS_LAUNCH_OK();
+        if (i > 0) {
+            hipLaunchKernelGGL(pack_weight_flipped_kernel, dim3(nblk((long)g.cout[i] * g.cin[i] * 9)), dim3(256), 0, st,
+                               p->w[i], g.cout[i], g.cin[i], s->wr + g.wt_off[i]);
+            LAS_LAUNCH_OK();
+        }
     }
     const float* in[4] = {x, s->y1, s->p1, s->y3};
     float* outs[4] = {s->y1, s->y2, s->y3, s->y4};
     for (int i = 0; i < 4; ++i) {
         // the raw features are [B][T][C_in*F] with the delta channel outermost (view_input, asr.py:533-544)
-        const VStr si = i == 0 ? VStr{(long)T * D, (long)D, 1, (long)d.F} : nhwc(g.T[i], g.F[i], g.cin[i]);
-        if ((rc = im2col(in[i], si, g.T[i], g.F[i], g.cin[i], d.Kp[i], g.rows[i], s->col, st)) != LAS_OK) return rc;
-        rc = las_gemm(prec, 0, 1, (int)g.rows[i], g.cout[i], d.Kp[i], 1.f, s->col, d.Kp[i], 0, s->wr + g.wr_off[i],
-                      d.Kp[i], 0, 0.f, outs[i], g.cout[i], 0, p->b[i], LAS_ACT_RELU, 1, stream);
+        if (i == 0) {
+            const VStr si = VStr{(long)T * D, (long)D, 1, (long)d.F};
+            if ((rc = im2col(in[i], si, g.T[i], g.F[i], g.cin[i], d.Kp[i], g.rows[i], s->col, st)) != LAS_OK) return rc;
+            rc = las_gemm(prec, 0, 1, (int)g.rows[i], g.cout[i], d.Kp[i], 1.f, s->col, d.Kp[i], 0, s->wr + g.wr_off[i],
+                          d.Kp[i], 0, 0.f, outs[i], g.cout[i], 0, p->b[i], LAS_ACT_RELU, 1, stream);
+        } else {
+            rc = las_conv3x3_fwd(prec, in[i], g.T[i], g.F[i], g.cin[i], g.rows[i], s->wr + g.wr_off[i], g.cout[i], p->b[i],
+                                 nullptr, 0, outs[i], st);
+        }
         if (rc != LAS_OK) return rc;
         if (i == 1) {
             hipLaunchKernelGGL(pool_fwd_kernel, dim3(nblk(d.R2 * C1)), dim3(256), 0, st, s->y2, d.Tt, d.F, C1, d.R2 * C1,
@@ -302,30 +326,36 @@ extern "C" int las_vgg_bwd(int prec, const float* x, const float* dout, int B, i
         const int Co = g.cout[i], Ci = g.cin[i], Kp = d.Kp[i];
         const long R = g.rows[i];
         if ((rc = las_colsum(dy, Co, (int)R, Co, 1.f, gr->db[i], stream)) != LAS_OK) return rc;
-        const VStr si = i == 0 ? VStr{(long)T * D, (long)D, 1, (long)d.F} : nhwc(g.T[i], g.F[i], Ci);
-        if ((rc = im2col(in[i], si, g.T[i], g.F[i], Ci, Kp, R, s->col, st)) != LAS_OK) return rc;
-        rc = las_gemm(prec, 1, 0, Co, Kp, (int)R, 1.f, dy, Co, 0, s->col, Kp, 0, 0.f, s->dwr, Kp, 0, nullptr,
-                      LAS_ACT_NONE, 1, stream);
+        if (i == 0) {
+            const VStr si = VStr{(long)T * D, (long)D, 1, (long)d.F};
+            if ((rc = im2col(in[0], si, g.T[0], g.F[0], Ci, Kp, R, s->col, st)) != LAS_OK) return rc;
+            rc = las_gemm(prec, 1, 0, Co, Kp, (int)R, 1.f, dy, Co, 0, s->col, Kp, 0, 0.f, s->dwr, Kp, 0, nullptr,
+                          LAS_ACT_NONE, 1, stream);
+        } else {
+            rc = las_conv3x3_wgrad(prec, dy, Co, in[i], g.T[i], g.F[i], Ci, R, s->dwr, st);
+        }
         if (rc != LAS_OK) return rc;
         hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(nblk((long)Co * Ci * 9)), dim3(256), 0, st, s->dwr, Co, Ci, Kp, gr->dw[i]);
         LAS_LAUNCH_OK();
-        if (i == 0 && !dx) break;
-        rc = las_gemm(prec, 0, 0, (int)R, Kp, Co, 1.f, dy, Co, 0, s->wr + g.wr_off[i], Kp, 0, 0.f, s->col, Kp, 0, nullptr,
-                      LAS_ACT_NONE, 1, stream);
-        if (rc != LAS_OK) return rc;
         if (i == 0) {
+            if (!dx) break;
+            rc = las_gemm(prec, 0, 0, (int)R, Kp, Co, 1.f, dy, Co, 0, s->wr + g.wr_off[0], Kp, 0, 0.f, s->col, Kp, 0, nullptr,
+                          LAS_ACT_NONE, 1, stream);
+            if (rc != LAS_OK) return rc;
             rc = col2im(s->col, g.T[0], g.F[0], Ci, Kp, R, nullptr, dx, VStr{(long)T * D, (long)D, 1, (long)d.F}, st);
             if (rc != LAS_OK) return rc;
-        } else if (i == 2) {
-            // conv3's input is pool1's output: gather d p1, then route it through pool1 and conv2's ReLU
-            if ((rc = col2im(s->col, g.T[2], g.F[2], Ci, Kp, R, nullptr, other, nhwc(g.T[2], g.F[2], Ci), st)) != LAS_OK) return rc;
+            break;
+        }
+        // data gradient: the same convolution on dY with the flipped weights; conv4 / conv2 inputs are ReLU outputs of
+        // the layer below (mask fused), conv3's input is pool1's output (routed through pool1 and conv2's ReLU next)
+        rc = las_conv3x3_fwd(prec, dy, g.T[i], g.F[i], Co, R, s->wr + g.wt_off[i], Ci, nullptr, i == 2 ? nullptr : in[i], 1,
+                             other, st);
+        if (rc != LAS_OK) return rc;
+        if (i == 2) {
             hipLaunchKernelGGL(pool_bwd_kernel, dim3(nblk(d.R1 * C1)), dim3(256), 0, st, other, nhwc(d.T2, d.F2, C1), s->idx1,
                                s->y2, d.Tt, d.F, C1, d.R1 * C1, dy);
             LAS_LAUNCH_OK();
-            continue;                                   // dy (= ga or gb) now holds d pre-activation of conv2
-        } else {
-            // conv4 / conv2: the input is the ReLU output of the layer below
-            if ((rc = col2im(s->col, g.T[i], g.F[i], Ci, Kp, R, in[i], other, nhwc(g.T[i], g.F[i], Ci), st)) != LAS_OK) return rc;
+            continue;                                   // dy now holds d pre-activation of conv2
         }
         float* tmp = dy; dy = other; other = tmp;
     }

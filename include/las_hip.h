@@ -215,8 +215,9 @@ int las_token_acc(const int32_t* pred, const int64_t* y, int Ly, int B, int L, f
  * c*(F/4)+f as the reference's transpose+view.  The T%4 tail frames are dropped; lengths are the caller's (//4).
  * Activations are kept channels-last [B][T][F][C]; all buffers are caller-owned (sizes from las_vgg_get_dims):
  *   y1,y2 [R1][64]  p1 [R2][64]  y3,y4 [R2][128]  idx1 [R2][64] bytes  idx2 [R3][128] bytes
- *   col [col_floats] scratch (3x3 patch matrix of one convolution, refilled per convolution)
- *   wr [wr_floats] weights re-ordered to [C_out][tap][C_in] (written by fwd, read by bwd)
+ *   col [col_floats] scratch (zero-padded 3x3 patch matrix of conv1, the only one materialised)
+ *   wr [wr_floats] weights re-ordered to [C_out][tap][C_in], then conv2..4 again as [C_in][8-tap][C_out] for the
+ *      data gradient (written by fwd, read by bwd)
  *   dwr [wr_floats], ga, gb [R1][64]   (bwd only)
  * w[i] [C_out][C_in][3][3] and b[i] [C_out] are the reference's conv{1..4}.weight/bias; bwd ACCUMULATES into
  * dw[i]/db[i] and, when dx != NULL, writes dx [B][T][D] (zero in the dropped tail). */

@@ -44,15 +44,33 @@ __global__ __launch_bounds__(256) void cell_pw_bwd(int B, int C, const float* __
     dc_carry[i] = dc * fg;
 }
 
-// grid (NCH, B): d a[t'] = enc[b,t',:] . dctx[b,:] (+ carry from the later step's location conv); the consumed
-// carry row is zeroed for reuse two steps later.
+// grid (NCH, B): d a[t'] = enc[b,t',:] . dctx[b,:]  (+ in loc mode the gradient that reaches this step's attention
+// through the NEXT step's location convolution, gathered from that step's saved d f:
+//   d prev[tau] = sum_c sum_k w[c][k] * df[c][tau + K - k] ).
 __global__ __launch_bounds__(256) void att_bwd_da(int Tp, int E, int TC, const float* __restrict__ enc,
                                                   const int32_t* __restrict__ lens, const float* __restrict__ dctx,
-                                                  long ld_dctx, float* __restrict__ extra, float* __restrict__ da) {
+                                                  long ld_dctx, const float* __restrict__ df_next,
+                                                  const float* __restrict__ conv_w, float* __restrict__ da) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.y, t0 = blockIdx.x * TC, t1 = min(t0 + TC, Tp), len = lens[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Ep = (E + 3) & ~3, W = TC + 2 * LOC_K;
+    float* cw_l = sm + Ep;                           // [10][201]
+    float* df_l = cw_l + LOC_C * LOC_W;              // [10][TC + 200]: df[c][t0 - K + i]
+    if (t0 >= len) {                                 // whole chunk beyond the utterance
+        for (int t = t0 + threadIdx.x; t < t1; t += 256) da[(long)b * Tp + t] = 0.f;
+        return;
+    }
     for (int i = threadIdx.x; i < E; i += 256) sm[i] = dctx[(long)b * ld_dctx + i];
+    if (df_next) {
+        fill_batched<8>(conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+        const float* __restrict__ fp = df_next + (long)b * LOC_C * Tp;
+        for (int i = threadIdx.x; i < LOC_C * W; i += 256) {
+            const int c = i / W, j = i - c * W, t = t0 - LOC_K + j;
+            const float v = fp[(long)c * Tp + min(max(t, 0), Tp - 1)];
+            df_l[i] = (t >= 0 && t < Tp) ? v : 0.f;
+        }
+    }
     __syncthreads();
     const bool vec = (E & 3) == 0 && ((((uintptr_t)enc) & 15) == 0);
     for (int t = t0 + wave; t < t1; t += 4) {
@@ -76,13 +94,23 @@ __global__ __launch_bounds__(256) void att_bwd_da(int Tp, int E, int TC, const f
             } else {
                 for (int i = lane; i < E; i += 64) acc += p[i] * sm[i];
             }
+            if (df_next) {
+                // local index of df[c][tau + K - k] is (tau - t0) + 2K - k
+                const float* __restrict__ dl = df_l + (t - t0) + 2 * LOC_K;
+                float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < LOC_C; ++c) {
+                    const float* __restrict__ cw = cw_l + c * LOC_W;
+                    const float* __restrict__ dc = dl + c * W;
+                    g0 += cw[lane] * dc[-lane] + cw[lane + 64] * dc[-(lane + 64)];
+                    g1 += cw[lane + 128] * dc[-(lane + 128)];
+                    if (lane < LOC_W - 192) g1 += cw[lane + 192] * dc[-(lane + 192)];
+                }
+                acc += g0 + g1;
+            }
             acc = wave_sum(acc);
-            if (extra) acc += extra[(long)b * Tp + t];
         }
-        if (lane == 0) {
-            da[(long)b * Tp + t] = acc;
-            if (extra) extra[(long)b * Tp + t] = 0.f;
-        }
+        if (lane == 0) da[(long)b * Tp + t] = acc;
     }
 }
 
@@ -93,29 +121,29 @@ struct AttBwdArgs {
     const float* da;          // [B][Tp]
     const float* q;           // [B][A]
     float* dq_pre;            // [B][A]  (+=, atomics; already multiplied by 1-q^2)
-    float* de;                // [B][Tp] (dot: saved for the d psi contraction)
+    float* de;                // [B][Tp] d loss / d energy of this step (saved for the post-loop contractions)
     // loc
-    const float* prev;        // [B][Tp] attention of the previous step (input of the conv)
-    const float* f;           // [B][10][Tp]
-    const float* s;           // [B][Tp][A]
-    const float* conv_w; const float* w_lp; const float* w_e;
-    float* dpsi;              // [B][Tp][A] (+=, block-owned rows)
-    float* extra_out;         // [B][Tp] (+=, atomics): d loss / d prev
-    float* acc;               // [B][acc_stride]: d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad | d conv [10*201]
-    long acc_stride;
-    int dbg;                  // timing experiments only (LAS_DBG_ATT): bit0 skip main loop, bit1 skip acc flush,
-                              // bit2 skip conv backward, bit3 skip the LDS fills
+    const float* f;           // [B][10][Tp] location features of this step
+    const float* s;           // [B][Tp][A] tanh(psi + q + u)
+    const float* w_lp; const float* w_e;
+    float* df;                // [B][10][Tp] d loss / d f of this step (caller-zeroed; frames < len written)
 };
 
-// grid (NCH, B)
+// grid (NCH, B).  Only what the NEXT (earlier) step needs stays on the sequential chain: d e (softmax backward),
+// d q (sum over frames of d z) and d f (sum over the attention dim of d u * W_lp).  Everything that is a plain sum
+// over the L steps -- d psi, d w_e, d b_e, d W_lp, d conv_w -- is left to att_loc_post / att_conv_wgrad after the
+// loop, from the saved s / f / d e / d f.
 template <bool LOC, int AI>
 __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[32];
     const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (a.dbg & 16) return;
     float* de_l = sm;                                // [TC]
+    if (t0 >= len) {                                 // nothing flows through frames beyond the utterance
+        for (int t = t0 + threadIdx.x; t < t1; t += 256) a.de[(long)b * a.Tp + t] = 0.f;
+        return;
+    }
     // softmax backward needs the full-row dot  sum_t a[t] * da[t]
     float dot = 0.f;
     for (int i = threadIdx.x; i < len; i += 256) dot += a.att[(long)b * a.Tp + i] * a.da[(long)b * a.Tp + i];
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         float v = 0.f;
         if (t < t1 && t < len) v = ATT_SCALE * a.att[(long)b * a.Tp + t] * (a.da[(long)b * a.Tp + t] - dot);
         de_l[i] = v;
-        if (!LOC && t < t1) a.de[(long)b * a.Tp + t] = v;
+        if (t < t1) a.de[(long)b * a.Tp + t] = v;
     }
     __syncthreads();
     if (!LOC) {
@@ -145,73 +173,44 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         }
         return;
     }
-    const int tcv = min(t1, len) - t0;               // valid frames in this chunk
-    if (tcv <= 0 || (a.dbg & 32)) return;                            // whole chunk beyond the utterance: nothing flows
+    const int tcv = min(t1, len) - t0;               // valid frames in this chunk (> 0 here)
     float* we_l = de_l + a.TC;                       // [A]
     float* wlp_l = we_l + a.A;                       // [10][A]
-    float* cw_l = wlp_l + 48 * a.A;                  // [10][201]   (wlp_l region is 48A long: reused for the partials)
-    float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
-    float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]  saved location features of this chunk
-    float* df_l = f_l + LOC_C * a.TC;                // [10][TC]
-    // per-wave partial sums {dq, dwe, dwlp[10]} laid out [wave][12][A] (lane-contiguous: conflict-free plain stores);
-    // the region starts on the w_lp tile, which is dead once the main loop is over
-    float* acc_l = wlp_l;
-    if (!(a.dbg & 8)) {
+    float* f_l = wlp_l + LOC_C * a.A;                // [10][TC]
+    float* dq_l = f_l + LOC_C * a.TC;                // [4][A] per-wave partials
+    // all rows this wave touches (<= ATT_ROWS, chunks are <= 20 frames) are requested up front: one round trip
+    constexpr int ATT_ROWS = 5;
+    float svr[ATT_ROWS][AI];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
+        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+        for (int k = 0; k < AI; ++k) svr[r][k] = sp[min(lane + 64 * k, a.A - 1)];
+    }
     fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
     fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
-    fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
-    }
     {
-        const float* __restrict__ pr = a.prev + (long)b * a.Tp;
-        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
-            const int t = t0 - LOC_K + i;
-            const float v = pr[min(max(t, 0), a.Tp - 1)];
-            prev_l[i] = (t >= 0 && t < a.Tp) ? v : 0.f;
-        }
         const float* __restrict__ fp = a.f + (long)b * LOC_C * a.Tp;
         for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
             const int c = i / a.TC, tt = i - c * a.TC;
             const float v = fp[(long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
             f_l[i] = (tt < tcv) ? v : 0.f;
-            df_l[i] = 0.f;
         }
     }
     __syncthreads();
-    if (a.dbg & 64) return;
-    float dq_r[AI], dwe_r[AI], dwlp_r[AI][LOC_C];
+    float dq_r[AI];
 #pragma unroll
-    for (int k = 0; k < AI; ++k) {
-        dq_r[k] = 0.f; dwe_r[k] = 0.f;
-#pragma unroll
-        for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
-    }
-    float dbe = 0.f;
-    // all rows this wave touches (<= ATT_ROWS, chunks are <= 20 frames) are requested up front: one round trip
-    constexpr int ATT_ROWS = 5;
-    float svr[ATT_ROWS][AI], dpr[ATT_ROWS][AI];
-#pragma unroll
-    for (int r = 0; r < ATT_ROWS; ++r) {
-        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
-        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
-        const float* __restrict__ dpp = a.dpsi + ((long)b * a.Tp + t) * a.A;
-#pragma unroll
-        for (int k = 0; k < AI; ++k) {
-            const int i = min(lane + 64 * k, a.A - 1);
-            svr[r][k] = sp[i];
-            dpr[r][k] = dpp[i];
-        }
-    }
+    for (int k = 0; k < AI; ++k) dq_r[k] = 0.f;
+    float* __restrict__ dfg = a.df + (long)b * LOC_C * a.Tp;
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) {
         const int tt = wave + 4 * r;
-        if (tt >= tcv || (a.dbg & 1)) break;
-        const int t = t0 + tt;
+        if (tt >= tcv) break;
         const float de = de_l[tt];
-        dbe += de;
         float fc[LOC_C], dfc[LOC_C];
 #pragma unroll
         for (int c = 0; c < LOC_C; ++c) { fc[c] = f_l[c * a.TC + tt]; dfc[c] = 0.f; }
-        float* __restrict__ dp = a.dpsi + ((long)b * a.Tp + t) * a.A;
 #pragma unroll
         for (int k = 0; k < AI; ++k) {
             const int i = lane + 64 * k;
@@ -223,67 +222,216 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
                 const float sv = svr[r][k];
                 const float dz = de * we_l[i] * (1.f - sv * sv);
                 dq_r[k] += dz;
-                dp[i] = dpr[r][k] + dz;
-                dwe_r[k] += de * sv;
                 const float du = dz * (1.f - u * u);
 #pragma unroll
-                for (int c = 0; c < LOC_C; ++c) { dwlp_r[k][c] += du * fc[c]; dfc[c] += du * wlp_l[c * a.A + i]; }
+                for (int c = 0; c < LOC_C; ++c) dfc[c] += du * wlp_l[c * a.A + i];
             }
         }
 #pragma unroll
         for (int c = 0; c < LOC_C; ++c) {
             const float v = wave_sum(dfc[c]);
-            if (lane == 0) df_l[c * a.TC + tt] = v;
+            if (lane == 0) dfg[(long)c * a.Tp + t0 + tt] = v;
         }
     }
-    // ---- block reduction of the per-lane accumulators: per-wave partials, then a summing pass
-    __syncthreads();                                 // every wave is done reading wlp_l
+#pragma unroll
+    for (int k = 0; k < AI; ++k) {
+        const int i = lane + 64 * k;
+        if (i < a.A) dq_l[wave * a.A + i] = dq_r[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.A; i += 256) {
+        const float v = dq_l[i] + dq_l[a.A + i] + dq_l[2 * a.A + i] + dq_l[3 * a.A + i];
+        const float qv = a.q[(long)b * a.A + i];
+        atomicAdd(&a.dq_pre[(long)b * a.A + i], v * (1.f - qv * qv));
+    }
+}
+
+struct LocPostArgs {
+    int B, Tp, A, TC, L;
+    const int32_t* lens;
+    const float* de;          // [L][B][Tp]
+    const float* f;           // [L][B][10][Tp]
+    const float* s;           // [L][B][Tp][A]
+    const float* w_lp; const float* w_e;
+    float* dpsi;              // [B][Tp][A]   (caller-zeroed; rows < len written)
+    float* acc;               // [B][acc_stride]: d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad | d conv [10*201]  (+=)
+    long acc_stride;
+};
+
+// grid (NCH, B): the sums over the L steps that are off the sequential chain, in one pass over the saved s:
+//   d psi[b,t,:] = sum_l dz_l,  d w_e = sum de_l * s_l,  d b_e = sum de_l,  d W_lp = sum du_l (x) f_l
+// with dz_l = de_l * w_e * (1 - s_l^2), du_l = dz_l * (1 - u_l^2), u_l = tanh(W_lp f_l) recomputed.
+template <int AI>
+__global__ __launch_bounds__(256) void att_loc_post(LocPostArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[4];
+    const int b = blockIdx.y, t0 = blockIdx.x * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
+    const int tcv = min(t1, len) - t0;
+    if (tcv <= 0) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* we_l = sm;                                // [A]
+    float* wlp_l = we_l + a.A;                       // [10][A], later the [4][12][A] per-wave partials
+    fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
+    fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
+    __syncthreads();
+    constexpr int ROWS = 5;
+    float wlp_r[AI][LOC_C], we_r[AI];
+#pragma unroll
+    for (int k = 0; k < AI; ++k) {
+        const int i = min(lane + 64 * k, a.A - 1);
+        we_r[k] = we_l[i];
+#pragma unroll
+        for (int c = 0; c < LOC_C; ++c) wlp_r[k][c] = wlp_l[c * a.A + i];
+    }
+    float dps[ROWS][AI], dwe_r[AI], dwlp_r[AI][LOC_C];
+#pragma unroll
+    for (int k = 0; k < AI; ++k) {
+        dwe_r[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) dps[r][k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
+    }
+    float dbe = 0.f;
+    const long step_s = (long)a.B * a.Tp * a.A, step_f = (long)a.B * LOC_C * a.Tp, step_e = (long)a.B * a.Tp;
+    auto load = [&](float (&sv)[ROWS][AI], int l) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int t = min(t0 + wave + 4 * r, t0 + tcv - 1);
+            const float* __restrict__ sp = a.s + l * step_s + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+            for (int k = 0; k < AI; ++k) sv[r][k] = sp[min(lane + 64 * k, a.A - 1)];
+        }
+    };
+    auto compute = [&](const float (&sv)[ROWS][AI], int l) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int tt = wave + 4 * r;
+            if (tt >= tcv) break;
+            const float de = a.de[l * step_e + (long)b * a.Tp + t0 + tt];     // wave-uniform: scalar loads
+            dbe += de;
+            float fc[LOC_C];
+#pragma unroll
+            for (int c = 0; c < LOC_C; ++c) fc[c] = a.f[l * step_f + ((long)b * LOC_C + c) * a.Tp + t0 + tt];
+#pragma unroll
+            for (int k = 0; k < AI; ++k) {
+                float u = 0.f;
+#pragma unroll
+                for (int c = 0; c < LOC_C; ++c) u += wlp_r[k][c] * fc[c];
+                u = fast_tanh(u);
+                const float s_ = sv[r][k];
+                const float dz = de * we_r[k] * (1.f - s_ * s_);
+                dps[r][k] += dz;
+                dwe_r[k] += de * s_;
+                const float du = dz * (1.f - u * u);
+#pragma unroll
+                for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] += du * fc[c];
+            }
+        }
+    };
+    float svA[ROWS][AI], svB[ROWS][AI];
+    load(svA, 0);
+    for (int l = 0; l < a.L; l += 2) {
+        if (l + 1 < a.L) load(svB, l + 1);
+        compute(svA, l);
+        if (l + 1 < a.L) {
+            if (l + 2 < a.L) load(svA, l + 2);
+            compute(svB, l + 1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int tt = wave + 4 * r;
+        if (tt >= tcv) break;
+        float* __restrict__ dp = a.dpsi + ((long)b * a.Tp + t0 + tt) * a.A;
+#pragma unroll
+        for (int k = 0; k < AI; ++k) {
+            const int i = lane + 64 * k;
+            if (i < a.A) dp[i] = dps[r][k];
+        }
+    }
+    // ---- block reduction of the per-lane accumulators: per-wave partials [wave][11][A], then a summing pass
+    __syncthreads();                                 // (wlp_l is dead: the weights live in registers)
+    float* acc_l = wlp_l;
 #pragma unroll
     for (int k = 0; k < AI; ++k) {
         const int i = lane + 64 * k;
         if (i < a.A) {
-            float* o = acc_l + (long)wave * 12 * a.A + i;
-            o[0] = dq_r[k]; o[a.A] = dwe_r[k];
+            float* o = acc_l + (long)wave * 11 * a.A + i;
+            o[0] = dwe_r[k];
 #pragma unroll
-            for (int c = 0; c < LOC_C; ++c) o[(2 + c) * a.A] = dwlp_r[k][c];
+            for (int c = 0; c < LOC_C; ++c) o[(1 + c) * a.A] = dwlp_r[k][c];
         }
     }
-    dbe = wave_sum(dbe);
-    if (lane == 0) red[wave] = dbe;
+    if (lane == 0) red[wave] = dbe;                  // dbe is wave-uniform
     __syncthreads();
-    float* accg = a.acc + (long)b * a.acc_stride;      // one accumulator row per utterance (float atomics)
-    for (int i = threadIdx.x; i < ((a.dbg & 2) ? 0 : a.A * 12); i += 256) {
-        const int j = i / a.A, aa = i - j * a.A;         // j-major: coalesced LDS reads and global atomics
-        const float v = acc_l[i] + acc_l[12 * a.A + i] + acc_l[24 * a.A + i] + acc_l[36 * a.A + i];
-        if (j == 0) {
-            const float qv = a.q[(long)b * a.A + aa];
-            atomicAdd(&a.dq_pre[(long)b * a.A + aa], v * (1.f - qv * qv));
-        } else if (j == 1) {
-            atomicAdd(&accg[a.A * LOC_C + aa], v);
-        } else {
-            atomicAdd(&accg[(j - 2) * a.A + aa], v);     // [c][a]: contiguous atomics per wave
-        }
+    float* accg = a.acc + (long)b * a.acc_stride;
+    for (int i = threadIdx.x; i < a.A * 11; i += 256) {
+        const int j = i / a.A, aa = i - j * a.A;
+        const float v = acc_l[i] + acc_l[11 * a.A + i] + acc_l[22 * a.A + i] + acc_l[33 * a.A + i];
+        if (j == 0) atomicAdd(&accg[a.A * LOC_C + aa], v);
+        else atomicAdd(&accg[(j - 1) * a.A + aa], v);        // [c][a]: contiguous atomics per wave
     }
     if (threadIdx.x == 0) atomicAdd(&accg[a.A * LOC_C + a.A], red[0] + red[1] + red[2] + red[3]);
-    // ---- location conv backward
-    if (a.dbg & 4) return;
-    // d prev[tau] += sum_c sum_{t in chunk} w[c][tau - t + K] * df[c][t]
-    for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
-        const int tau = t0 - LOC_K + i;
-        if (tau < 0 || tau >= a.Tp) continue;
-        float acc = 0.f;
-        const int lo = max(0, tau - LOC_K - t0), hi = min(tcv, tau + LOC_K - t0 + 1);
-        for (int c = 0; c < LOC_C; ++c)
-            for (int tt = lo; tt < hi; ++tt) acc += cw_l[c * LOC_W + (tau - (t0 + tt) + LOC_K)] * df_l[c * a.TC + tt];
-        if (acc != 0.f) atomicAdd(&a.extra_out[(long)b * a.Tp + tau], acc);
+}
+
+// d conv_w[c][k] += sum over this block's (step, utterance) pairs of  sum_t df[c][t] * prev[t + k - K].
+// Thread = (c, 10 consecutive k): a sliding register window over prev gives 10 FMAs per two LDS reads.
+constexpr int CW_KPT = 10, CW_GROUPS = (LOC_W + CW_KPT - 1) / CW_KPT;       // 21 groups x 10 channels = 210 threads
+__global__ __launch_bounds__(256) void att_conv_wgrad(int B, int Tp, int L, int pairs_per_block,
+                                                      const int32_t* __restrict__ lens, const float* __restrict__ att,
+                                                      const float* __restrict__ df, float* __restrict__ acc,
+                                                      long acc_stride, long conv_off) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pl = sm;                                  // [Tp + 2K + CW_KPT] prev[i - K], zero outside
+    float* dl = pl + Tp + 2 * LOC_K + CW_KPT;        // [10][Tp]
+    const int c = threadIdx.x / CW_GROUPS, k0 = (threadIdx.x % CW_GROUPS) * CW_KPT;
+    const bool active = threadIdx.x < LOC_C * CW_GROUPS;
+    float accr[CW_KPT];
+#pragma unroll
+    for (int j = 0; j < CW_KPT; ++j) accr[j] = 0.f;
+    const long total = (long)L * B;
+    const long p0 = (long)blockIdx.x * pairs_per_block;
+    int last_b = -1;
+    for (long p = p0; p < min(total, p0 + pairs_per_block); ++p) {
+        const int b = (int)(p / L), l = (int)(p % L), len = lens[b];          // utterance-major: one flush per utterance
+        __syncthreads();
+        const float* __restrict__ pr = att + ((long)l * B + b) * Tp;            // attention fed to step l's conv
+        for (int i = threadIdx.x; i < Tp + 2 * LOC_K + CW_KPT; i += 256) {
+            const int t = i - LOC_K;
+            const float v = pr[min(max(t, 0), Tp - 1)];
+            pl[i] = (t >= 0 && t < Tp) ? v : 0.f;
+        }
+        const float* __restrict__ dp = df + ((long)l * B + b) * LOC_C * Tp;
+        for (int i = threadIdx.x; i < LOC_C * Tp; i += 256) dl[i] = dp[i];
+        __syncthreads();
+        if (active) {
+            if (last_b >= 0 && last_b != b) {        // flush the finished utterance's partial sums
+                float* o = acc + (long)last_b * acc_stride + conv_off + c * LOC_W + k0;
+#pragma unroll
+                for (int j = 0; j < CW_KPT; ++j)
+                    if (k0 + j < LOC_W) { atomicAdd(o + j, accr[j]); accr[j] = 0.f; }
+            }
+            float win[CW_KPT];
+#pragma unroll
+            for (int j = 0; j < CW_KPT; ++j) win[j] = pl[k0 + j];
+            const float* __restrict__ dr = dl + c * Tp;
+            for (int t = 0; t < len; ++t) {
+                const float d = dr[t];
+#pragma unroll
+                for (int j = 0; j < CW_KPT; ++j) accr[j] += d * win[j];
+#pragma unroll
+                for (int j = 0; j + 1 < CW_KPT; ++j) win[j] = win[j + 1];
+                win[CW_KPT - 1] = pl[t + 1 + k0 + CW_KPT - 1];
+            }
+        }
+        last_b = b;
     }
-    // d w[c][k] += sum_{t in chunk} df[c][t] * prev[t + k - K]
-    const long conv_off = ((a.A * LOC_C + a.A + 1 + 3) / 4) * 4;
-    for (int i = threadIdx.x; i < LOC_C * LOC_W; i += 256) {
-        const int c = i / LOC_W, k = i % LOC_W;
-        float acc = 0.f;
-        for (int tt = 0; tt < tcv; ++tt) acc += df_l[c * a.TC + tt] * prev_l[tt + k];
-        atomicAdd(&accg[conv_off + i], acc);
+    if (active && last_b >= 0) {
+        float* o = acc + (long)last_b * acc_stride + conv_off + c * LOC_W + k0;
+#pragma unroll
+        for (int j = 0; j < CW_KPT; ++j)
+            if (k0 + j < LOC_W) atomicAdd(o + j, accr[j]);
     }
 }
 
@@ -322,15 +470,18 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
     LAS_HIP(hipMemsetAsync(w.dc_carry, 0, sizeof(float) * NL * BC, st));
     LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
     if (loc) {
-        LAS_HIP(hipMemsetAsync(w.extra, 0, sizeof(float) * 2 * (size_t)B * Tp, st));
+        LAS_CHECK_ARG(w.df && w.de && w.dpsi && w.acc);
+        LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
         LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
         LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
     }
     size_t lds_e = sizeof(float) * (size_t)TC;
-    // [TC] de | [A] w_e | max([10A] w_lp, then [4][12][A] partials overlaid from here) ... the overlay may run over
-    // cw/prev/f/df, which must stay live for the conv backward, so it gets its own tail instead: size = 48A after w_e
-    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + 48 * (size_t)A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC);
-    if (lds_e > 160 * 1024) return LAS_E_UNSUPPORTED;
+    // [TC] de | [A] w_e | [10][A] w_lp | [10][TC] f | [4][A] dq partials
+    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * (size_t)A + LOC_C * TC + 4 * (size_t)A);
+    const size_t lds_da = sizeof(float) * (((size_t)E + 3) / 4 * 4 + (loc ? LOC_C * LOC_W + LOC_C * (TC + 2 * LOC_K) : 0));
+    const size_t lds_post = sizeof(float) * ((size_t)A + 44 * (size_t)A);
+    const size_t lds_cw = sizeof(float) * ((size_t)Tp + 2 * LOC_K + CW_KPT + LOC_C * (size_t)Tp);
+    if (lds_e > 160 * 1024 || lds_da > 64 * 1024 || (loc && (lds_post > 160 * 1024 || lds_cw > 160 * 1024))) return LAS_E_UNSUPPORTED;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
@@ -356,10 +507,10 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             }
         }
         // ---- attention of step t
-        float* extra_in = loc ? w.extra + (long)(t & 1) * B * Tp : nullptr;
-        float* extra_out = loc ? w.extra + (long)((t + 1) & 1) * B * Tp : nullptr;
-        hipLaunchKernelGGL(att_bwd_da, dim3(NCH, B), dim3(256), sizeof(float) * E, st, Tp, E, TC, enc, enc_len,
-                           w.dxin + (long)t * B * XI + C, XI, extra_in, w.da);
+        // the location conv of step t+1 read this step's attention: its saved d f carries that gradient back
+        const float* df_next = (loc && t + 1 < L) ? w.df + (long)(t + 1) * B * LOC_C * Tp : nullptr;
+        hipLaunchKernelGGL(att_bwd_da, dim3(NCH, B), dim3(256), lds_da, st, Tp, E, TC, enc, enc_len,
+                           w.dxin + (long)t * B * XI + C, XI, df_next, p->conv_w, w.da);
         LAS_LAUNCH_OK();
         AttBwdArgs a{};
         a.B = B; a.Tp = Tp; a.A = A; a.TC = TC; a.NCH = NCH;
@@ -368,20 +519,18 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         a.da = w.da;
         a.q = s.q + (long)t * B * A;
         a.dq_pre = w.dq_pre + (long)t * B * A;
-        a.de = loc ? nullptr : w.de + (long)t * B * Tp;
-        a.prev = s.att + (long)t * B * Tp;
+        a.de = w.de + (long)t * B * Tp;
         a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
         a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
-        a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e;
-        a.dpsi = w.dpsi; a.extra_out = extra_out; a.acc = w.acc; a.acc_stride = acc_stride;
-        { static const char* e = getenv("LAS_DBG_ATT"); a.dbg = e ? atoi(e) : 0; }
+        a.w_lp = p->w_lp; a.w_e = p->w_e;
+        a.df = loc ? w.df + (long)t * B * LOC_C * Tp : nullptr;
         if (!loc) {
             hipLaunchKernelGGL((att_bwd_energy<false, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
         } else {
 #define LAS_ATT_GO(AIV)                                                                                           \
     {                                                                                                             \
         auto k = att_bwd_energy<true, AIV>;                                                                       \
-        if (lds_e > 64 * 1024) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e)); \
+        if (lds_e > 64 * 1024 && t == L - 1) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e)); \
         hipLaunchKernelGGL(k, dim3(NCH, B), dim3(256), lds_e, st, a);                                             \
     }
             if (AI <= 1) LAS_ATT_GO(1) else if (AI <= 2) LAS_ATT_GO(2) else if (AI <= 4) LAS_ATT_GO(4)
@@ -397,6 +546,30 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
                                        nullptr, nullptr, st);
             if (rc) return rc;
         }
+    }
+    if (loc) {
+        // ---- sums over the L steps that are off the sequential chain
+        LocPostArgs q{};
+        q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
+        q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
+        q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
+#define LAS_POST_GO(AIV)                                                                                          \
+    {                                                                                                             \
+        auto k = att_loc_post<AIV>;                                                                               \
+        if (lds_post > 64 * 1024) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post)); \
+        hipLaunchKernelGGL(k, dim3(NCH, B), dim3(256), lds_post, st, q);                                          \
+    }
+        if (AI <= 1) LAS_POST_GO(1) else if (AI <= 2) LAS_POST_GO(2) else if (AI <= 4) LAS_POST_GO(4)
+        else if (AI <= 5) LAS_POST_GO(5) else LAS_POST_GO(8)
+#undef LAS_POST_GO
+        LAS_LAUNCH_OK();
+        const long conv_off = ((A * LOC_C + A + 1 + 3) / 4) * 4;
+        const int ppb = L < 8 ? L : 8;                                   // (step, utterance) pairs per workgroup
+        const long nblk = ((long)L * B + ppb - 1) / ppb;
+        if (lds_cw > 64 * 1024) LAS_HIP(hipFuncSetAttribute((const void*)att_conv_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cw));
+        hipLaunchKernelGGL(att_conv_wgrad, dim3((unsigned)nblk), dim3(256), lds_cw, st, B, Tp, L, ppb, enc_len, s.att, w.df,
+                           w.acc, acc_stride, conv_off);
+        LAS_LAUNCH_OK();
     }
     // embedding rows
     LAS_HIP(hipMemsetAsync(w.demb, 0, sizeof(float) * (size_t)d->V * C, st));

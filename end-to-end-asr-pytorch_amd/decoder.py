@@ -91,7 +91,7 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
 
 
 class DecBwdState(ctypes.Structure):
-    _fields_ = [(n, P) for n in ('dgates', 'dxin', 'dq_pre', 'de', 'dh_carry', 'dc_carry', 'd_below', 'da', 'extra',
+    _fields_ = [(n, P) for n in ('dgates', 'dxin', 'dq_pre', 'de', 'dh_carry', 'dc_carry', 'd_below', 'da', 'df',
                                  'dpsi', 'acc', 'demb')]
 
 
@@ -155,12 +155,10 @@ class DecoderFn(torch.autograd.Function):
         Bw = dict(dgates=torch.empty(NL, L, B, 4 * C, **f32), dxin=torch.empty(L, B, C + E, **f32),
                   dq_pre=torch.empty(L, B, A, **f32), dh_carry=torch.empty(NL, B, C, **f32),
                   dc_carry=torch.empty(NL, B, C, **f32), d_below=torch.empty(B, C, **f32), da=torch.empty(B, Tp, **f32),
-                  demb=torch.empty(V, C, **f32))
+                  demb=torch.empty(V, C, **f32), de=torch.empty(L, B, Tp, **f32))
         if loc:
-            Bw.update(extra=torch.empty(2, B, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
+            Bw.update(df=torch.empty(L, B, LOC_C, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
                       acc=torch.empty(B, accf, **f32))
-        else:
-            Bw['de'] = torch.empty(L, B, Tp, **f32)
         bw = DecBwdState()
         for k, v in Bw.items():
             setattr(bw, k, v.data_ptr())

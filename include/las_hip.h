@@ -150,13 +150,14 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
     float* dgates;                  /* [NL][L][B][4C]  d loss / d gate pre-activations */
     float* dxin;                    /* [L][B][C+E]     d loss / d cell-0 input (embedding | context) */
     float* dq_pre;                  /* [L][B][A]       d loss / d (phi h) before the tanh */
-    float* de;                      /* dot: [L][B][Tp] d loss / d energy */
+    float* de;                      /* [L][B][Tp] d loss / d energy */
     float* dh_carry;                /* [NL][B][C] */
     float* dc_carry;                /* [NL][B][C] */
     float* d_below;                 /* [B][C] scratch */
     float* da;                      /* [B][Tp] scratch */
-    float* extra;                   /* loc: [2][B][Tp] d loss / d prev_att carried between steps */
-    float* dpsi;                    /* loc: [B][Tp][A] accumulated d loss / d psi(enc) */
+    float* df;                      /* loc: [L][B][10][Tp] d loss / d location features of each step (carries the
+                                       gradient through the location conv to the previous step's attention) */
+    float* dpsi;                    /* loc: [B][Tp][A] d loss / d psi(enc), summed over the steps after the loop */
     float* acc;                     /* loc: [B][las_decoder_loc_acc_floats(A)] per-utterance partial sums:
                                        d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
     float* demb;                    /* [V][C] d loss / d embed.weight */

@@ -79,3 +79,62 @@ def test_decoder_forward(mods, prec, mode, B, Tp, E, A, C, NL, V, L):
     np.testing.assert_allclose(S['xin'][:, :, C:].cpu().numpy(), ctx_r, **tol)
     np.testing.assert_allclose(S['hs'][NL - 1, 1:].cpu().numpy(), top_r, **tol)
     assert np.array_equal(S['tok'].cpu().numpy(), y[:, :L].T)
+
+
+@pytest.mark.parametrize('mode,B,Tp,E,A,C,NL,V,L', [('loc', 5, 150, 48, 40, 32, 1, 31, 6), ('dot', 20, 75, 64, 32, 64, 2, 63, 5),
+                                                    ('loc', 24, 300, 640, 300, 320, 1, 31, 4), ('loc', 4, 45, 16, 70, 8, 2, 9, 3)])
+def test_decoder_backward(mods, mode, B, Tp, E, A, C, NL, V, L):
+    """BPTT of the whole loop (las_decoder_bwd + the post-loop contractions) vs autograd through the oracle's step
+    functions, f32 mode, at sizes with several attention chunks / lanes per row (incl. the C2 shape).  Every gradient
+    within 2e-4 of its largest entry + 2e-5."""
+    from oracle import las_ref as R
+    ops, dec = mods
+    rng = np.random.RandomState(B * 100 + Tp + 7)
+    loc = mode == 'loc'
+    W = rand_weights(rng, V, C, E, A, NL, loc)
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    # ---- oracle
+    Wt = {k: torch.tensor(v, requires_grad=True) for k, v in W.items()}
+    enc_t, psi_t = torch.tensor(enc, requires_grad=True), torch.tensor(psi, requires_grad=True)
+    hs = [torch.zeros(B, C) for _ in range(NL)]
+    cs = [torch.zeros(B, C) for _ in range(NL)]
+    st = R.attention_init(enc_t, lens, Wt)
+    st['psi'] = psi_t
+    tops = []
+    for t in range(L):
+        a, ctx = R.attention_step(hs[0], enc_t, st, Wt, mode)
+        tops.append(R.speller_step(torch.cat([Wt['embed.weight'][torch.tensor(y[:, t])], ctx], -1), hs, cs, Wt, NL))
+    (torch.stack(tops) * torch.tensor(G)).sum().backward()
+    # ---- HIP
+    names = dec.weight_names(NL, loc)
+    Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+    enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+    psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+    ops.set_precision('f32')
+    try:
+        h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                         torch.tensor(y, device=DEV), L, NL, loc, None, 0, *[Wg[k] for k in names])
+        (h_top * torch.tensor(G, device=DEV)).sum().backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+
+    def near(got, ref, what):
+        ref = ref.detach().numpy()
+        got = got.detach().cpu().numpy()
+        err, lim = np.abs(got - ref).max(), 2e-5 + 2e-4 * np.abs(ref).max()
+        assert err <= lim, (what, float(err), float(lim))
+    near(h_top, torch.stack(tops), 'h_top')
+    near(enc_g.grad, enc_t.grad, 'd enc')
+    near(psi_g.grad, psi_t.grad, 'd psi')
+    for k in names:
+        if k.startswith('char_trans'):
+            continue                                      # not used inside the loop
+        near(Wg[k].grad, Wt[k].grad, k)

@@ -24,3 +24,13 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f'host enqueue {1e3*(t1-t0)/N:.1f} ms/step ; wall incl. GPU drain {1e3*(t2-t0)/N:.1f} ms/step')
+if os.environ.get('LAS_HOST_PROFILE'):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(N): t.train_step(x, y, 1.0, host_lens=hl)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats('tottime').print_stats(28)
+    st.sort_stats('cumulative').print_stats(40)

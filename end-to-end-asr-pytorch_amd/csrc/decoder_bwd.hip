@@ -4,8 +4,7 @@
 // :410-457, Speller.forward :352-357).  Per step, newest first:
 //   cell pointwise bwd (per layer)           dgates from dh (top-layer grad + recurrent carry) and dc carry
 //   dgates * [W_ih | W_hh]                   skinny MFMA products on transposed weight copies
-//   d a = enc . d ctx (+ loc carry)          att_bwd_da       grid (T'-chunks, B)  HBM-bound on enc
-//   softmax bwd, energy bwd                  att_bwd_energy   grid (T'-chunks, B)  HBM-bound on psi / s
+//   d a = enc . d ctx (+ loc carry), softmax bwd, energy bwd     att_bwd_step  grid (T'-chunks, B)  HBM-bound on enc / s
 //   dh0_{t-1} += dq_pre * W_phi              skinny MFMA product (accumulate)
 // Sums over the L steps that are plain contractions (dW of every Linear/LSTMCell, d enc, d psi in dot mode)
 // are left to ONE las_gemm each after the loop, on the buffers this call fills.
@@ -44,59 +43,154 @@ __global__ __launch_bounds__(256) void cell_pw_bwd(int B, int C, const float* __
     dc_carry[i] = dc * fg;
 }
 
-// grid (NCH, B): d a[t'] = enc[b,t',:] . dctx[b,:]  (+ in loc mode the gradient that reaches this step's attention
-// through the NEXT step's location convolution, gathered from that step's saved d f:
-//   d prev[tau] = sum_c sum_k w[c][k] * df[c][tau + K - k] ).
-__global__ __launch_bounds__(256) void att_bwd_da(int Tp, int E, int TC, const float* __restrict__ enc,
-                                                  const int32_t* __restrict__ lens, const float* __restrict__ dctx,
-                                                  long ld_dctx, const float* __restrict__ df_next,
-                                                  const float* __restrict__ conv_w, float* __restrict__ da) {
+struct AttBwdArgs {
+    int B, Tp, E, A, TC, NCH;
+    const float* enc;         // [B][Tp][E]
+    const float* psi; const int32_t* lens;
+    const float* att;         // [B][Tp] this step's attention
+    const float* dctx; long ld_dctx;   // [B][E] d loss / d context of this step
+    const float* ctx; long ld_ctx;     // [B][E] this step's context (saved)
+    const float* q;           // [B][A]
+    float* dq_pre;            // [B][A]  (+=, atomics; already multiplied by 1-q^2)
+    float* de;                // [B][Tp] d loss / d energy of this step (saved for the post-loop contractions)
+    // loc
+    const float* f;           // [B][10][Tp] location features of this step
+    const float* s;           // [B][Tp][A] tanh(psi + q + u)
+    const float* w_lp; const float* w_e; const float* conv_w;
+    float* df;                // [B][10][Tp] d loss / d f of this step (caller-zeroed; frames < len written)
+    const float* df_next;     // [B][10][Tp] d f of step t+1 (NULL at the last step): the location conv of step t+1
+    const float* f_next;      //             read THIS step's attention, so its d f carries gradient back to it
+};
+
+// grid (NCH, B): attention backward of one step for a chunk of <= 20 frames of one utterance.
+//   d a[t] = enc[b,t,:] . dctx  +  sum_c sum_k w[c][k] * df_next[c][t + K - k]        (context + location-conv paths)
+//   d e[t] = 2 a[t] (d a[t] - dot),  dot = sum_t a[t] d a[t]
+// The softmax dot needs no other chunk:  sum_t a[t] enc[t] . dctx = ctx . dctx  with the saved context, and
+// sum_t a[t] * (conv-path term) = <df_next, f_next>  because f_next = conv(a).  Only what the NEXT (earlier) step
+// needs stays on the sequential chain: d e, d q (sum over frames of d z) and d f (sum over the attention dim of
+// d u * W_lp).  Everything that is a plain sum over the L steps -- d psi, d w_e, d b_e, d W_lp, d conv_w -- is left to
+// att_loc_post / att_conv_wgrad after the loop, from the saved s / f / d e / d f.
+// 8 waves per workgroup: a chunk's <= 20 frames are <= 3 per wave, which keeps the two per-frame phases short.
+constexpr int ATT_NW = 8, ATT_NT = 64 * ATT_NW;
+template <bool LOC, int AI>
+__global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.y, t0 = blockIdx.x * TC, t1 = min(t0 + TC, Tp), len = lens[b];
+    __shared__ float red[32];
+    const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int Ep = (E + 3) & ~3, W = TC + 2 * LOC_K;
-    float* cw_l = sm + Ep;                           // [10][201]
-    float* df_l = cw_l + LOC_C * LOC_W;              // [10][TC + 200]: df[c][t0 - K + i]
-    if (t0 >= len) {                                 // whole chunk beyond the utterance
-        for (int t = t0 + threadIdx.x; t < t1; t += 256) da[(long)b * Tp + t] = 0.f;
+    if (t0 >= len) {                                 // nothing flows through frames beyond the utterance
+        for (int t = t0 + threadIdx.x; t < t1; t += ATT_NT) a.de[(long)b * a.Tp + t] = 0.f;
         return;
     }
-    for (int i = threadIdx.x; i < E; i += 256) sm[i] = dctx[(long)b * ld_dctx + i];
-    if (df_next) {
-        fill_batched<8>(conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
-        const float* __restrict__ fp = df_next + (long)b * LOC_C * Tp;
-        for (int i = threadIdx.x; i < LOC_C * W; i += 256) {
-            const int c = i / W, j = i - c * W, t = t0 - LOC_K + j;
-            const float v = fp[(long)c * Tp + min(max(t, 0), Tp - 1)];
-            df_l[i] = (t >= 0 && t < Tp) ? v : 0.f;
+    const int tcv = min(t1, len) - t0;               // valid frames in this chunk (> 0 here)
+    const int Ep = (a.E + 3) & ~3, W = a.TC + 2 * LOC_K;
+    float* dctx_l = sm;                              // [Ep]
+    float* de_l = dctx_l + Ep;                       // [TC]
+    float* we_l = de_l + a.TC;                       // [A]
+    float* wlp_l = we_l + a.A;                       // [10][A]
+    float* f_l = wlp_l + LOC_C * a.A;                // [10][TC]
+    float* dq_l = f_l + LOC_C * a.TC;                // [ATT_NW][A] per-wave partials
+    float* cw_l = dq_l + ATT_NW * a.A;                    // [10][201]
+    float* dfh_l = cw_l + LOC_C * LOC_W;             // [10][TC + 200]: df_next[c][t0 - K + i]
+    // all s rows this wave touches (<= ATT_ROWS, chunks are <= 20 frames) are requested up front: one round trip
+    constexpr int ATT_ROWS = (20 + ATT_NW - 1) / ATT_NW;
+    float svr[ATT_ROWS][AI];
+    if (LOC) {
+#pragma unroll
+        for (int r = 0; r < ATT_ROWS; ++r) {
+            const int t = min(t0 + wave + ATT_NW * r, a.Tp - 1);
+            const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+            for (int k = 0; k < AI; ++k) svr[r][k] = sp[min(lane + 64 * k, a.A - 1)];
         }
     }
-    __syncthreads();
-    const bool vec = (E & 3) == 0 && ((((uintptr_t)enc) & 15) == 0);
-    for (int t = t0 + wave; t < t1; t += 4) {
-        float acc = 0.f;
-        if (t < len) {
-            const float* __restrict__ p = enc + ((long)b * Tp + t) * E;
-            if (vec) {
-                float a0 = 0.f, a1 = 0.f;
-                int i = lane;
-                for (; i + 64 < E / 4; i += 128) {
-                    const float4 v0 = ((const float4*)p)[i], v1 = ((const float4*)p)[i + 64];
-                    const float4 w0 = ((const float4*)sm)[i], w1 = ((const float4*)sm)[i + 64];
-                    a0 += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w;
-                    a1 += v1.x * w1.x + v1.y * w1.y + v1.z * w1.z + v1.w * w1.w;
-                }
-                for (; i < E / 4; i += 64) {
-                    const float4 v0 = ((const float4*)p)[i], w0 = ((const float4*)sm)[i];
-                    a0 += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w;
-                }
-                acc = a0 + a1;
-            } else {
-                for (int i = lane; i < E; i += 64) acc += p[i] * sm[i];
+    // ... and so are this wave's enc rows (<= 4 float4 per lane and row: E <= 1024 on this path)
+    const bool vec = (a.E & 3) == 0 && a.E <= 1024 && ((((uintptr_t)a.enc) & 15) == 0);
+    constexpr int EV = 4;
+    float4 er[ATT_ROWS][EV];
+    if (vec) {
+#pragma unroll
+        for (int r = 0; r < ATT_ROWS; ++r) {
+            const int t = min(t0 + wave + ATT_NW * r, t0 + tcv - 1);
+            const float4* __restrict__ p = (const float4*)(a.enc + ((long)b * a.Tp + t) * a.E);
+#pragma unroll
+            for (int k = 0; k < EV; ++k) er[r][k] = p[min(lane + 64 * k, a.E / 4 - 1)];
+        }
+    }
+    float att_r[ATT_ROWS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) att_r[r] = a.att[(long)b * a.Tp + min(t0 + wave + ATT_NW * r, t0 + tcv - 1)];
+    // ---- staging + the softmax dot
+    float part = 0.f;
+    for (int i = threadIdx.x; i < a.E; i += ATT_NT) {
+        const float d = a.dctx[(long)b * a.ld_dctx + i];
+        dctx_l[i] = d;
+        part += d * a.ctx[(long)b * a.ld_ctx + i];
+    }
+    const bool carry = LOC && a.df_next != nullptr;
+    if (LOC) {
+        fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
+        fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
+        const float* __restrict__ fp = a.f + (long)b * LOC_C * a.Tp;
+        for (int i = threadIdx.x; i < LOC_C * a.TC; i += ATT_NT) {
+            const int c = i / a.TC, tt = i - c * a.TC;
+            const float v = fp[(long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
+            f_l[i] = (tt < tcv) ? v : 0.f;
+        }
+        if (carry) {
+            fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
+            const float* __restrict__ dn = a.df_next + (long)b * LOC_C * a.Tp;
+            const float* __restrict__ fn = a.f_next + (long)b * LOC_C * a.Tp;
+            constexpr int HU = (LOC_C * (20 + 2 * LOC_K) + ATT_NT - 1) / ATT_NT;       // chunks are <= 20 frames
+            float hv[HU];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {           // all halo loads in flight before the first LDS store
+                const int i = min((int)threadIdx.x + ATT_NT * u, LOC_C * W - 1);
+                const int c = i / W, j = i - c * W, t = t0 - LOC_K + j;
+                const float v = dn[(long)c * a.Tp + min(max(t, 0), a.Tp - 1)];
+                hv[u] = (t >= 0 && t < a.Tp) ? v : 0.f;
             }
-            if (df_next) {
-                // local index of df[c][tau + K - k] is (tau - t0) + 2K - k
-                const float* __restrict__ dl = df_l + (t - t0) + 2 * LOC_K;
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const int i = threadIdx.x + ATT_NT * u;
+                if (i < LOC_C * W) dfh_l[i] = hv[u];
+            }
+            const int n = LOC_C * a.Tp;                                      // <df_next, f_next>
+            int i = threadIdx.x;
+            for (; i + 3 * ATT_NT < n; i += 4 * ATT_NT) {
+                const float d0 = dn[i], d1 = dn[i + ATT_NT], d2 = dn[i + 2 * ATT_NT], d3 = dn[i + 3 * ATT_NT];
+                const float f0 = fn[i], f1 = fn[i + ATT_NT], f2 = fn[i + 2 * ATT_NT], f3 = fn[i + 3 * ATT_NT];
+                part += d0 * f0 + d1 * f1 + d2 * f2 + d3 * f3;
+            }
+            for (; i < n; i += ATT_NT) part += dn[i] * fn[i];
+        }
+    }
+    const float dot = block_sum(part, red);          // (its barriers also publish the LDS staging)
+    // ---- d a, d e for this wave's frames
+    float de_r[ATT_ROWS];
+#pragma unroll
+    for (int r = 0; r < ATT_ROWS; ++r) {
+        const int tt = wave + ATT_NW * r, t = t0 + tt;
+        de_r[r] = 0.f;
+        if (tt >= a.TC || t >= t1) break;
+        if (tt < tcv) {
+            float acc = 0.f;
+            const float* __restrict__ p = a.enc + ((long)b * a.Tp + t) * a.E;
+            if (vec) {
+#pragma unroll
+                for (int k = 0; k < EV; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < a.E / 4) {
+                        const float4 v = er[r][k], w = ((const float4*)dctx_l)[i];
+                        acc += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+                    }
+                }
+            } else {
+                for (int i = lane; i < a.E; i += 64) acc += p[i] * dctx_l[i];
+            }
+            if (carry) {
+                // local index of df_next[c][t + K - k] is tt + 2K - k
+                const float* __restrict__ dl = dfh_l + tt + 2 * LOC_K;
                 float g0 = 0.f, g1 = 0.f;
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) {
@@ -109,57 +203,18 @@ __global__ __launch_bounds__(256) void att_bwd_da(int Tp, int E, int TC, const f
                 acc += g0 + g1;
             }
             acc = wave_sum(acc);
+            de_r[r] = ATT_SCALE * att_r[r] * (acc - dot);
         }
-        if (lane == 0) da[(long)b * Tp + t] = acc;
+        if (lane == 0) {
+            a.de[(long)b * a.Tp + t] = de_r[r];
+            if (!LOC) de_l[tt] = de_r[r];
+        }
     }
-}
-
-struct AttBwdArgs {
-    int B, Tp, A, TC, NCH;
-    const float* psi; const int32_t* lens;
-    const float* att;         // [B][Tp] this step's attention
-    const float* da;          // [B][Tp]
-    const float* q;           // [B][A]
-    float* dq_pre;            // [B][A]  (+=, atomics; already multiplied by 1-q^2)
-    float* de;                // [B][Tp] d loss / d energy of this step (saved for the post-loop contractions)
-    // loc
-    const float* f;           // [B][10][Tp] location features of this step
-    const float* s;           // [B][Tp][A] tanh(psi + q + u)
-    const float* w_lp; const float* w_e;
-    float* df;                // [B][10][Tp] d loss / d f of this step (caller-zeroed; frames < len written)
-};
-
-// grid (NCH, B).  Only what the NEXT (earlier) step needs stays on the sequential chain: d e (softmax backward),
-// d q (sum over frames of d z) and d f (sum over the attention dim of d u * W_lp).  Everything that is a plain sum
-// over the L steps -- d psi, d w_e, d b_e, d W_lp, d conv_w -- is left to att_loc_post / att_conv_wgrad after the
-// loop, from the saved s / f / d e / d f.
-template <bool LOC, int AI>
-__global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float red[32];
-    const int b = blockIdx.y, ch = blockIdx.x, t0 = ch * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* de_l = sm;                                // [TC]
-    if (t0 >= len) {                                 // nothing flows through frames beyond the utterance
-        for (int t = t0 + threadIdx.x; t < t1; t += 256) a.de[(long)b * a.Tp + t] = 0.f;
-        return;
-    }
-    // softmax backward needs the full-row dot  sum_t a[t] * da[t]
-    float dot = 0.f;
-    for (int i = threadIdx.x; i < len; i += 256) dot += a.att[(long)b * a.Tp + i] * a.da[(long)b * a.Tp + i];
-    dot = block_sum(dot, red);
-    for (int i = threadIdx.x; i < a.TC; i += 256) {
-        const int t = t0 + i;
-        float v = 0.f;
-        if (t < t1 && t < len) v = ATT_SCALE * a.att[(long)b * a.Tp + t] * (a.da[(long)b * a.Tp + t] - dot);
-        de_l[i] = v;
-        if (t < t1) a.de[(long)b * a.Tp + t] = v;
-    }
-    __syncthreads();
     if (!LOC) {
+        __syncthreads();
         // dq[a] = sum_t de[t] * psi[b,t,a]
-        const int tv = min(t1, len);
-        for (int i = threadIdx.x; i < a.A; i += 256) {
+        const int tv = t0 + tcv;
+        for (int i = threadIdx.x; i < a.A; i += ATT_NT) {
             float acc0 = 0.f, acc1 = 0.f;
             const float* __restrict__ p = a.psi + ((long)b * a.Tp) * a.A + i;
             int t = t0;
@@ -173,41 +228,15 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         }
         return;
     }
-    const int tcv = min(t1, len) - t0;               // valid frames in this chunk (> 0 here)
-    float* we_l = de_l + a.TC;                       // [A]
-    float* wlp_l = we_l + a.A;                       // [10][A]
-    float* f_l = wlp_l + LOC_C * a.A;                // [10][TC]
-    float* dq_l = f_l + LOC_C * a.TC;                // [4][A] per-wave partials
-    // all rows this wave touches (<= ATT_ROWS, chunks are <= 20 frames) are requested up front: one round trip
-    constexpr int ATT_ROWS = 5;
-    float svr[ATT_ROWS][AI];
-#pragma unroll
-    for (int r = 0; r < ATT_ROWS; ++r) {
-        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
-        const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
-#pragma unroll
-        for (int k = 0; k < AI; ++k) svr[r][k] = sp[min(lane + 64 * k, a.A - 1)];
-    }
-    fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
-    fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
-    {
-        const float* __restrict__ fp = a.f + (long)b * LOC_C * a.Tp;
-        for (int i = threadIdx.x; i < LOC_C * a.TC; i += 256) {
-            const int c = i / a.TC, tt = i - c * a.TC;
-            const float v = fp[(long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
-            f_l[i] = (tt < tcv) ? v : 0.f;
-        }
-    }
-    __syncthreads();
     float dq_r[AI];
 #pragma unroll
     for (int k = 0; k < AI; ++k) dq_r[k] = 0.f;
     float* __restrict__ dfg = a.df + (long)b * LOC_C * a.Tp;
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) {
-        const int tt = wave + 4 * r;
+        const int tt = wave + ATT_NW * r;
         if (tt >= tcv) break;
-        const float de = de_l[tt];
+        const float de = de_r[r];
         float fc[LOC_C], dfc[LOC_C];
 #pragma unroll
         for (int c = 0; c < LOC_C; ++c) { fc[c] = f_l[c * a.TC + tt]; dfc[c] = 0.f; }
@@ -239,8 +268,10 @@ __global__ __launch_bounds__(256) void att_bwd_energy(AttBwdArgs a) {
         if (i < a.A) dq_l[wave * a.A + i] = dq_r[k];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < a.A; i += 256) {
-        const float v = dq_l[i] + dq_l[a.A + i] + dq_l[2 * a.A + i] + dq_l[3 * a.A + i];
+    for (int i = threadIdx.x; i < a.A; i += ATT_NT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) v += dq_l[w * a.A + i];
         const float qv = a.q[(long)b * a.A + i];
         atomicAdd(&a.dq_pre[(long)b * a.A + i], v * (1.f - qv * qv));
     }
@@ -258,121 +289,84 @@ struct LocPostArgs {
     long acc_stride;
 };
 
-// grid (NCH, B): the sums over the L steps that are off the sequential chain, in one pass over the saved s:
+// grid (ceil(Tp / POST_TC), B), one wave per 64 attention dims (blockDim = 64 * ceil(A/64)): the sums over the L
+// steps that are off the sequential chain, in one pass over the saved s:
 //   d psi[b,t,:] = sum_l dz_l,  d w_e = sum de_l * s_l,  d b_e = sum de_l,  d W_lp = sum du_l (x) f_l
 // with dz_l = de_l * w_e * (1 - s_l^2), du_l = dz_l * (1 - u_l^2), u_l = tanh(W_lp f_l) recomputed.
-template <int AI>
-__global__ __launch_bounds__(256) void att_loc_post(LocPostArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ float red[4];
-    const int b = blockIdx.y, t0 = blockIdx.x * a.TC, t1 = min(t0 + a.TC, a.Tp), len = a.lens[b];
+// A lane owns one attention dim for POST_TC frames, so its running sums are ~20 registers, >= 8 waves per SIMD hide
+// the HBM latency of the s rows, and no cross-wave reduction is needed (lanes add their sums with coalesced atomics).
+constexpr int POST_TC = 4;
+__global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
+    const int b = blockIdx.y, t0 = blockIdx.x * POST_TC, t1 = min(t0 + POST_TC, a.Tp), len = a.lens[b];
     const int tcv = min(t1, len) - t0;
     if (tcv <= 0) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* we_l = sm;                                // [A]
-    float* wlp_l = we_l + a.A;                       // [10][A], later the [4][12][A] per-wave partials
-    fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
-    fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
-    __syncthreads();
-    constexpr int ROWS = 5;
-    float wlp_r[AI][LOC_C], we_r[AI];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = wave * 64 + lane, ic = min(i, a.A - 1);
+    float wlp_r[LOC_C];
 #pragma unroll
-    for (int k = 0; k < AI; ++k) {
-        const int i = min(lane + 64 * k, a.A - 1);
-        we_r[k] = we_l[i];
+    for (int c = 0; c < LOC_C; ++c) wlp_r[c] = a.w_lp[ic * LOC_C + c];
+    const float we_r = a.w_e[ic];
+    float dps[POST_TC], dwlp_r[LOC_C], dwe_r = 0.f, dbe = 0.f;
 #pragma unroll
-        for (int c = 0; c < LOC_C; ++c) wlp_r[k][c] = wlp_l[c * a.A + i];
-    }
-    float dps[ROWS][AI], dwe_r[AI], dwlp_r[AI][LOC_C];
+    for (int r = 0; r < POST_TC; ++r) dps[r] = 0.f;
 #pragma unroll
-    for (int k = 0; k < AI; ++k) {
-        dwe_r[k] = 0.f;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) dps[r][k] = 0.f;
-#pragma unroll
-        for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] = 0.f;
-    }
-    float dbe = 0.f;
+    for (int c = 0; c < LOC_C; ++c) dwlp_r[c] = 0.f;
     const long step_s = (long)a.B * a.Tp * a.A, step_f = (long)a.B * LOC_C * a.Tp, step_e = (long)a.B * a.Tp;
-    auto load = [&](float (&sv)[ROWS][AI], int l) {
+    // per (step, frame) side data {de, f[0..9]}: lanes 0..10 of one vector load, broadcast with v_readlane when used
+    const int j = min(lane, LOC_C);                  // 0: de, 1..10: f[j-1]
+    const float* __restrict__ auxp = j == 0 ? a.de + (long)b * a.Tp : a.f + ((long)b * LOC_C + (j - 1)) * a.Tp;
+    const long aux_step = j == 0 ? step_e : step_f;
+    const float* __restrict__ sp0 = a.s + (long)b * a.Tp * a.A + ic;
+    auto load = [&](float (&sv)[POST_TC], float (&aux)[POST_TC], int l) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int t = min(t0 + wave + 4 * r, t0 + tcv - 1);
-            const float* __restrict__ sp = a.s + l * step_s + ((long)b * a.Tp + t) * a.A;
-#pragma unroll
-            for (int k = 0; k < AI; ++k) sv[r][k] = sp[min(lane + 64 * k, a.A - 1)];
+        for (int r = 0; r < POST_TC; ++r) {
+            const int t = min(t0 + r, t0 + tcv - 1);
+            sv[r] = sp0[l * step_s + (long)t * a.A];
+            aux[r] = auxp[l * aux_step + t];
         }
     };
-    auto compute = [&](const float (&sv)[ROWS][AI], int l) {
+    auto compute = [&](const float (&sv)[POST_TC], const float (&aux)[POST_TC]) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int tt = wave + 4 * r;
-            if (tt >= tcv) break;
-            const float de = a.de[l * step_e + (long)b * a.Tp + t0 + tt];     // wave-uniform: scalar loads
+        for (int r = 0; r < POST_TC; ++r) {
+            if (r >= tcv) break;
+            const float de = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[r]), 0));
             dbe += de;
-            float fc[LOC_C];
+            float fc[LOC_C], u = 0.f;
 #pragma unroll
-            for (int c = 0; c < LOC_C; ++c) fc[c] = a.f[l * step_f + ((long)b * LOC_C + c) * a.Tp + t0 + tt];
-#pragma unroll
-            for (int k = 0; k < AI; ++k) {
-                float u = 0.f;
-#pragma unroll
-                for (int c = 0; c < LOC_C; ++c) u += wlp_r[k][c] * fc[c];
-                u = fast_tanh(u);
-                const float s_ = sv[r][k];
-                const float dz = de * we_r[k] * (1.f - s_ * s_);
-                dps[r][k] += dz;
-                dwe_r[k] += de * s_;
-                const float du = dz * (1.f - u * u);
-#pragma unroll
-                for (int c = 0; c < LOC_C; ++c) dwlp_r[k][c] += du * fc[c];
+            for (int c = 0; c < LOC_C; ++c) {
+                fc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[r]), c + 1));
+                u += wlp_r[c] * fc[c];
             }
+            u = fast_tanh(u);
+            const float s_ = sv[r];
+            const float dz = de * we_r * (1.f - s_ * s_);
+            dps[r] += dz;
+            dwe_r += de * s_;
+            const float du = dz * (1.f - u * u);
+#pragma unroll
+            for (int c = 0; c < LOC_C; ++c) dwlp_r[c] += du * fc[c];
         }
     };
-    float svA[ROWS][AI], svB[ROWS][AI];
-    load(svA, 0);
+    float svA[POST_TC], svB[POST_TC], auxA[POST_TC], auxB[POST_TC];
+    load(svA, auxA, 0);
     for (int l = 0; l < a.L; l += 2) {
-        if (l + 1 < a.L) load(svB, l + 1);
-        compute(svA, l);
+        if (l + 1 < a.L) load(svB, auxB, l + 1);
+        compute(svA, auxA);
         if (l + 1 < a.L) {
-            if (l + 2 < a.L) load(svA, l + 2);
-            compute(svB, l + 1);
+            if (l + 2 < a.L) load(svA, auxA, l + 2);
+            compute(svB, auxB);
         }
     }
+    if (i < a.A) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const int tt = wave + 4 * r;
-        if (tt >= tcv) break;
-        float* __restrict__ dp = a.dpsi + ((long)b * a.Tp + t0 + tt) * a.A;
+        for (int r = 0; r < POST_TC; ++r)
+            if (r < tcv) a.dpsi[((long)b * a.Tp + t0 + r) * a.A + i] = dps[r];
+        float* accg = a.acc + (long)b * a.acc_stride;
+        atomicAdd(&accg[a.A * LOC_C + i], dwe_r);
 #pragma unroll
-        for (int k = 0; k < AI; ++k) {
-            const int i = lane + 64 * k;
-            if (i < a.A) dp[i] = dps[r][k];
-        }
+        for (int c = 0; c < LOC_C; ++c) atomicAdd(&accg[c * a.A + i], dwlp_r[c]);      // [c][a]: contiguous per wave
+        if (i == 0) atomicAdd(&accg[a.A * LOC_C + a.A], dbe);
     }
-    // ---- block reduction of the per-lane accumulators: per-wave partials [wave][11][A], then a summing pass
-    __syncthreads();                                 // (wlp_l is dead: the weights live in registers)
-    float* acc_l = wlp_l;
-#pragma unroll
-    for (int k = 0; k < AI; ++k) {
-        const int i = lane + 64 * k;
-        if (i < a.A) {
-            float* o = acc_l + (long)wave * 11 * a.A + i;
-            o[0] = dwe_r[k];
-#pragma unroll
-            for (int c = 0; c < LOC_C; ++c) o[(1 + c) * a.A] = dwlp_r[k][c];
-        }
-    }
-    if (lane == 0) red[wave] = dbe;                  // dbe is wave-uniform
-    __syncthreads();
-    float* accg = a.acc + (long)b * a.acc_stride;
-    for (int i = threadIdx.x; i < a.A * 11; i += 256) {
-        const int j = i / a.A, aa = i - j * a.A;
-        const float v = acc_l[i] + acc_l[11 * a.A + i] + acc_l[22 * a.A + i] + acc_l[33 * a.A + i];
-        if (j == 0) atomicAdd(&accg[a.A * LOC_C + aa], v);
-        else atomicAdd(&accg[(j - 1) * a.A + aa], v);        // [c][a]: contiguous atomics per wave
-    }
-    if (threadIdx.x == 0) atomicAdd(&accg[a.A * LOC_C + a.A], red[0] + red[1] + red[2] + red[3]);
 }
 
 // d conv_w[c][k] += sum over this block's (step, utterance) pairs of  sum_t df[c][t] * prev[t + k - K].
@@ -475,13 +469,11 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
         LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
     }
-    size_t lds_e = sizeof(float) * (size_t)TC;
-    // [TC] de | [A] w_e | [10][A] w_lp | [10][TC] f | [4][A] dq partials
-    if (loc) lds_e = sizeof(float) * ((size_t)TC + A + LOC_C * (size_t)A + LOC_C * TC + 4 * (size_t)A);
-    const size_t lds_da = sizeof(float) * (((size_t)E + 3) / 4 * 4 + (loc ? LOC_C * LOC_W + LOC_C * (TC + 2 * LOC_K) : 0));
-    const size_t lds_post = sizeof(float) * ((size_t)A + 44 * (size_t)A);
+    // [E] dctx | [TC] de | loc: [A] w_e | [10][A] w_lp | [10][TC] f | [8][A] dq partials | [10][201] conv_w | [10][TC+200] df halo
+    size_t lds_e = sizeof(float) * (((size_t)E + 3) / 4 * 4 + TC);
+    if (loc) lds_e += sizeof(float) * (A + LOC_C * (size_t)A + LOC_C * TC + ATT_NW * (size_t)A + LOC_C * LOC_W + LOC_C * (TC + 2 * LOC_K));
     const size_t lds_cw = sizeof(float) * ((size_t)Tp + 2 * LOC_K + CW_KPT + LOC_C * (size_t)Tp);
-    if (lds_e > 160 * 1024 || lds_da > 64 * 1024 || (loc && (lds_post > 160 * 1024 || lds_cw > 160 * 1024))) return LAS_E_UNSUPPORTED;
+    if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
@@ -507,31 +499,33 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             }
         }
         // ---- attention of step t
-        // the location conv of step t+1 read this step's attention: its saved d f carries that gradient back
-        const float* df_next = (loc && t + 1 < L) ? w.df + (long)(t + 1) * B * LOC_C * Tp : nullptr;
-        hipLaunchKernelGGL(att_bwd_da, dim3(NCH, B), dim3(256), lds_da, st, Tp, E, TC, enc, enc_len,
-                           w.dxin + (long)t * B * XI + C, XI, df_next, p->conv_w, w.da);
-        LAS_LAUNCH_OK();
         AttBwdArgs a{};
-        a.B = B; a.Tp = Tp; a.A = A; a.TC = TC; a.NCH = NCH;
-        a.psi = psi; a.lens = enc_len;
+        a.B = B; a.Tp = Tp; a.E = E; a.A = A; a.TC = TC; a.NCH = NCH;
+        a.enc = enc; a.psi = psi; a.lens = enc_len;
         a.att = s.att + (long)(t + 1) * B * Tp;
-        a.da = w.da;
+        a.dctx = w.dxin + (long)t * B * XI + C; a.ld_dctx = XI;
+        a.ctx = s.xin + (long)t * B * XI + C; a.ld_ctx = XI;
         a.q = s.q + (long)t * B * A;
         a.dq_pre = w.dq_pre + (long)t * B * A;
         a.de = w.de + (long)t * B * Tp;
-        a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
-        a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
-        a.w_lp = p->w_lp; a.w_e = p->w_e;
-        a.df = loc ? w.df + (long)t * B * LOC_C * Tp : nullptr;
+        if (loc) {
+            a.f = s.f + (long)t * B * LOC_C * Tp;
+            a.s = s.s + (long)t * B * Tp * A;
+            a.w_lp = p->w_lp; a.w_e = p->w_e; a.conv_w = p->conv_w;
+            a.df = w.df + (long)t * B * LOC_C * Tp;
+            if (t + 1 < L) {
+                a.df_next = w.df + (long)(t + 1) * B * LOC_C * Tp;
+                a.f_next = s.f + (long)(t + 1) * B * LOC_C * Tp;
+            }
+        }
         if (!loc) {
-            hipLaunchKernelGGL((att_bwd_energy<false, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            hipLaunchKernelGGL((att_bwd_step<false, 1>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
         } else {
 #define LAS_ATT_GO(AIV)                                                                                           \
     {                                                                                                             \
-        auto k = att_bwd_energy<true, AIV>;                                                                       \
+        auto k = att_bwd_step<true, AIV>;                                                                         \
         if (lds_e > 64 * 1024 && t == L - 1) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e)); \
-        hipLaunchKernelGGL(k, dim3(NCH, B), dim3(256), lds_e, st, a);                                             \
+        hipLaunchKernelGGL(k, dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);                                          \
     }
             if (AI <= 1) LAS_ATT_GO(1) else if (AI <= 2) LAS_ATT_GO(2) else if (AI <= 4) LAS_ATT_GO(4)
             else if (AI <= 5) LAS_ATT_GO(5) else LAS_ATT_GO(8)
@@ -553,15 +547,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
         q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
-#define LAS_POST_GO(AIV)                                                                                          \
-    {                                                                                                             \
-        auto k = att_loc_post<AIV>;                                                                               \
-        if (lds_post > 64 * 1024) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post)); \
-        hipLaunchKernelGGL(k, dim3(NCH, B), dim3(256), lds_post, st, q);                                          \
-    }
-        if (AI <= 1) LAS_POST_GO(1) else if (AI <= 2) LAS_POST_GO(2) else if (AI <= 4) LAS_POST_GO(4)
-        else if (AI <= 5) LAS_POST_GO(5) else LAS_POST_GO(8)
-#undef LAS_POST_GO
+        hipLaunchKernelGGL(att_loc_post, dim3((Tp + POST_TC - 1) / POST_TC, B), dim3(64 * AI), 0, st, q);
         LAS_LAUNCH_OK();
         const long conv_off = ((A * LOC_C + A + 1 + 3) / 4) * 4;
         const int ppb = L < 8 ? L : 8;                                   // (step, utterance) pairs per workgroup

@@ -53,24 +53,37 @@ struct AttArgs {
     float* e;                 // [B][Tp]
     float* f;                 // [B][10][Tp]  (loc, saved)
     float* s;                 // [B][Tp][A]   (loc, saved)
-    int dbg;                  // timing experiments only (LAS_DBG_ATTF): 1 skip main loop, 2 skip conv, 4 skip fills, 8 return
 };
 
-// grid (NCH, B): energies of T'-chunk [t0, t0+TC) of utterance b
-constexpr int ATT_ROWS = 5;     // rows of a T'-chunk per wave: chunks are <= 20 frames (att_chunks), 4 waves
+// grid (NCH, B): energies of T'-chunk [t0, t0+TC) of utterance b.  8 waves per workgroup: a chunk's <= 20 frames
+// (att_chunks) are <= 3 per wave, and the location convolution's 10 x TC outputs are split over two half-ranges of
+// taps per output so that all 512 threads work on it.
+constexpr int ATTF_NW = 8, ATTF_NT = 64 * ATTF_NW;
+constexpr int ATT_ROWS = (20 + ATTF_NW - 1) / ATTF_NW;
 
 template <bool LOC, int AI>     // AI = ceil(A / 64) rounded up to {1,2,4,5,8}
-__global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
+__global__ __launch_bounds__(ATTF_NT) void att_energy_fwd(AttArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.y, t0 = blockIdx.x * a.TC, len = a.lens[b];
     const int t1 = min(t0 + a.TC, a.Tp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (a.dbg & 8) return;
     float* q_l = sm;                                 // [A]
+    // every psi row this wave will touch is requested before anything else (one memory round trip, overlapped
+    // with the staging and the convolution below)
+    float pv[ATT_ROWS][AI];
+    if (LOC) {
+#pragma unroll
+        for (int r = 0; r < ATT_ROWS; ++r) {
+            const int t = min(t0 + wave + ATTF_NW * r, a.Tp - 1);
+            const float* __restrict__ p = a.psi + ((long)b * a.Tp + t) * a.A;
+#pragma unroll
+            for (int k = 0; k < AI; ++k) pv[r][k] = p[min(lane + 64 * k, a.A - 1)];
+        }
+    }
     fill_batched<2>(a.q + (long)b * a.A, a.A, [&](int i, float v) { q_l[i] = v; });
     if (!LOC) {
         __syncthreads();
-        for (int t = t0 + wave; t < t1; t += 4) {
+        for (int t = t0 + wave; t < t1; t += ATTF_NW) {
             float acc = 0.f;
             if (t < len) {
                 const float* p = a.psi + ((long)b * a.Tp + t) * a.A;
@@ -86,50 +99,51 @@ __global__ __launch_bounds__(256) void att_energy_fwd(AttArgs a) {
     float* cw_l = wlp_l + LOC_C * a.A;               // [10][201]
     float* prev_l = cw_l + LOC_C * LOC_W;            // [TC + 200]
     float* f_l = prev_l + a.TC + 2 * LOC_K;          // [10][TC]
-    if (!(a.dbg & 4)) {
+    float* fh_l = f_l + LOC_C * a.TC;                // [10][TC] second half-range of taps
     fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
     fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
-    fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
-    }
+    fill_batched<4>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
     {
         const float* __restrict__ pr = a.prev + (long)b * a.Tp;
-        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += 256) {
+        for (int i = threadIdx.x; i < a.TC + 2 * LOC_K; i += ATTF_NT) {
             const int t = t0 - LOC_K + i;
             const float v = pr[min(max(t, 0), a.Tp - 1)];
             prev_l[i] = (t >= 0 && t < a.Tp) ? v : 0.f;
         }
     }
     __syncthreads();
-    // location features f[c][t] = sum_k w[c][k] * prev[t + k - K]
-    for (int i = threadIdx.x; i < ((a.dbg & 2) ? 0 : LOC_C * a.TC); i += 256) {
-        const int c = i / a.TC, tt = i % a.TC;
-        float acc = 0.f;
-        if (t0 + tt < t1) {
-            const float* w = cw_l + c * LOC_W;
-            const float* p = prev_l + tt;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;             // 3 chains x unroll: LDS latency, not issue, bounds this loop
+    // location features f[c][t] = sum_k w[c][k] * prev[t + k - K]: thread = (output, half of the taps)
+    {
+        const int half = threadIdx.x >= ATTF_NT / 2, i = threadIdx.x - half * (ATTF_NT / 2);
+        if (i < LOC_C * a.TC) {
+            const int c = i / a.TC, tt = i % a.TC;
+            float acc = 0.f;
+            if (t0 + tt < t1) {
+                constexpr int H0 = 102;              // taps [0,102) and [102,201): 3 x 34 and 3 x 33
+                const int k0 = half ? H0 : 0, k1 = half ? LOC_W : H0;
+                const float* w = cw_l + c * LOC_W;
+                const float* p = prev_l + tt;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;         // 3 chains x unroll: LDS latency, not issue, bounds this loop
 #pragma unroll 8
-            for (int k = 0; k + 2 < LOC_W; k += 3) { a0 += w[k] * p[k]; a1 += w[k + 1] * p[k + 1]; a2 += w[k + 2] * p[k + 2]; }
-            acc = (a0 + a1) + a2;                           // LOC_W = 201 = 3 * 67
-            a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] = acc;
+                for (int k = k0; k + 2 < k1; k += 3) { a0 += w[k] * p[k]; a1 += w[k + 1] * p[k + 1]; a2 += w[k + 2] * p[k + 2]; }
+                acc = (a0 + a1) + a2;
+            }
+            (half ? fh_l : f_l)[c * a.TC + tt] = acc;
         }
-        f_l[c * a.TC + tt] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LOC_C * a.TC; i += ATTF_NT) {
+        const int c = i / a.TC, tt = i % a.TC;
+        const float v = f_l[i] + fh_l[i];
+        f_l[i] = v;
+        if (t0 + tt < t1) a.f[((long)b * LOC_C + c) * a.Tp + t0 + tt] = v;
     }
     __syncthreads();
     const float be = a.b_e[0];
-    // every psi row this wave will touch is requested before the first one is used (one memory round trip)
-    float pv[ATT_ROWS][AI];
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) {
-        const int t = min(t0 + wave + 4 * r, a.Tp - 1);
-        const float* __restrict__ p = a.psi + ((long)b * a.Tp + t) * a.A;
-#pragma unroll
-        for (int k = 0; k < AI; ++k) pv[r][k] = p[min(lane + 64 * k, a.A - 1)];
-    }
-#pragma unroll
-    for (int r = 0; r < ATT_ROWS; ++r) {
-        const int t = t0 + wave + 4 * r;
-        if (t >= t1 || (a.dbg & 1)) break;
+        const int t = t0 + wave + ATTF_NW * r;
+        if (t >= t1) break;
         float acc = 0.f;
         const int tt = t - t0;
         if (t < len) {
@@ -274,7 +288,7 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
     const int NCH = att_chunks(Tp), TC = (Tp + NCH - 1) / NCH, ECH = (E + 63) / 64;
     if (TC > 20) return LAS_E_UNSUPPORTED;
     size_t lds_e = sizeof(float) * (size_t)A;
-    if (loc) lds_e = sizeof(float) * ((size_t)2 * A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + LOC_C * TC);
+    if (loc) lds_e = sizeof(float) * ((size_t)2 * A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC);
     if (lds_e > 64 * 1024) return LAS_E_UNSUPPORTED;
     const size_t lds_s = sizeof(float) * ((size_t)Tp + 32 + 256);
     if (lds_s > 64 * 1024) return LAS_E_UNSUPPORTED;
@@ -292,15 +306,14 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
         a.e = s.ebuf;
         a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
         a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
-        { static const char* e = getenv("LAS_DBG_ATTF"); a.dbg = e ? atoi(e) : 0; }
-        if (!loc) hipLaunchKernelGGL((att_energy_fwd<false, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
+        if (!loc) hipLaunchKernelGGL((att_energy_fwd<false, 1>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
         else {
             const int AI = (A + 63) / 64;
-            if (AI <= 1) hipLaunchKernelGGL((att_energy_fwd<true, 1>), dim3(NCH, B), dim3(256), lds_e, st, a);
-            else if (AI <= 2) hipLaunchKernelGGL((att_energy_fwd<true, 2>), dim3(NCH, B), dim3(256), lds_e, st, a);
-            else if (AI <= 4) hipLaunchKernelGGL((att_energy_fwd<true, 4>), dim3(NCH, B), dim3(256), lds_e, st, a);
-            else if (AI <= 5) hipLaunchKernelGGL((att_energy_fwd<true, 5>), dim3(NCH, B), dim3(256), lds_e, st, a);
-            else if (AI <= 8) hipLaunchKernelGGL((att_energy_fwd<true, 8>), dim3(NCH, B), dim3(256), lds_e, st, a);
+            if (AI <= 1) hipLaunchKernelGGL((att_energy_fwd<true, 1>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
+            else if (AI <= 2) hipLaunchKernelGGL((att_energy_fwd<true, 2>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
+            else if (AI <= 4) hipLaunchKernelGGL((att_energy_fwd<true, 4>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
+            else if (AI <= 5) hipLaunchKernelGGL((att_energy_fwd<true, 5>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
+            else if (AI <= 8) hipLaunchKernelGGL((att_energy_fwd<true, 8>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
             else return LAS_E_UNSUPPORTED;
         }
         LAS_LAUNCH_OK();

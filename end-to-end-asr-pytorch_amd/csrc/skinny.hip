@@ -70,8 +70,34 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
     }
 }
 
+// Epilogue operands of a thread's FIRST output element (bias, old output when accumulating, previous cell state):
+// requested at kernel entry so that their memory round trip overlaps the weight stream instead of following the
+// reduction barrier.
+struct SkinnyPre { float bias[4]; float old; };
+template <int NWAVES>
+__device__ __forceinline__ SkinnyPre skinny_prefetch(const SkinnyArgs& a, int blk) {
+    SkinnyPre p;
+    p.bias[0] = p.bias[1] = p.bias[2] = p.bias[3] = 0.f; p.old = 0.f;
+    const int e = threadIdx.x;
+    if (a.mode != 2) {
+        const int b = min(e >> 4, a.B - 1), n = min(blk * 16 + (e & 15), a.N - 1);
+        if (a.bias0) p.bias[0] = a.bias0[n];
+        if (a.bias1) p.bias[0] += a.bias1[n];
+        if (a.accumulate) p.old = a.out[(long)b * a.ldo + n];
+    } else {
+        const int b = min(e >> 2, a.B - 1), u = min(blk * 4 + (e & 3), a.C - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (a.bias0) p.bias[g] = a.bias0[g * a.C + u];
+            if (a.bias1) p.bias[g] += a.bias1[g * a.C + u];
+        }
+        p.old = a.c_prev[(long)b * a.C + u];
+    }
+    return p;
+}
+
 template <int NB, int NWAVES>
-__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float* __restrict__ Gl, int blk) {
+__device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float* __restrict__ Gl, int blk, const SkinnyPre& pre0) {
     auto gsum = [&](int b, int c) -> float {
         float v = 0.f;
 #pragma unroll
@@ -87,11 +113,16 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
         for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
             const int b = e >> 4, c = e & 15, row = wrow(c);
             if (row < 0) continue;
+            const bool first = e == (int)threadIdx.x;
             float v = gsum(b, c);
-            if (a.bias0) v += a.bias0[row];
-            if (a.bias1) v += a.bias1[row];
             float* o = a.out + (long)b * a.ldo + row;
-            if (a.accumulate) v += *o;
+            if (first) {
+                v += pre0.bias[0] + pre0.old;
+            } else {
+                if (a.bias0) v += a.bias0[row];
+                if (a.bias1) v += a.bias1[row];
+                if (a.accumulate) v += *o;
+            }
             if (a.mode == 1) v = tanhf(v);
             *o = v;
         }
@@ -99,17 +130,23 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
         for (int e = threadIdx.x; e < a.B * 4; e += NWAVES * 64) {
             const int b = e >> 2, jj = e & 3, u = blk * 4 + jj;
             if (u >= a.C) continue;
+            const bool first = e == (int)threadIdx.x;
             float pre[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = g * 4 + jj, row = g * a.C + u;
                 float v = gsum(b, c);
-                if (a.bias0) v += a.bias0[row];
-                if (a.bias1) v += a.bias1[row];
+                if (first) {
+                    v += pre0.bias[g];
+                } else {
+                    if (a.bias0) v += a.bias0[row];
+                    if (a.bias1) v += a.bias1[row];
+                }
                 pre[g] = v;
             }
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-            const float cn = fg * a.c_prev[(long)b * a.C + u] + ig * gg;
+            const float cp = first ? pre0.old : a.c_prev[(long)b * a.C + u];
+            const float cn = fg * cp + ig * gg;
             a.c_out[(long)b * a.C + u] = cn;
             a.h_out[(long)b * a.C + u] = og * tanhf(cn);
             float* go = a.gates_out + (long)b * 4 * a.C;
@@ -132,6 +169,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
     T* Bl = Al + NB * 16 * ld;                // [16][ld]
     float* Gl = (float*)(Bl + 16 * ld);       // [4][NB*16][17]
     const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const SkinnyPre pre0 = skinny_prefetch<4>(a, blk);
 
     // W row of tile column c
     auto wrow = [&](int c) -> int {
@@ -172,7 +210,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    skinny_epilogue<NB, 4>(a, Gl, blk);
+    skinny_epilogue<NB, 4>(a, Gl, blk, pre0);
 }
 
 // ---- direct variant: both operands go global -> registers -> MFMA, no LDS staging, no barriers before the
@@ -191,6 +229,7 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         return n < a.N ? n : -1;
     };
     const int row = wrow(fr);
+    const SkinnyPre pre0 = skinny_prefetch<DW>(a, blk);
     f32x4 acc[NB];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -198,53 +237,59 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         const u32x4 r = {pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w)};
         return __builtin_bit_cast(bf16x8, r);
     };
-    // global k-step index over the concatenated segments; wave w takes k-steps w, w+DW, ...
-    // Every load is unconditional from a clamped (always valid) address; out-of-range pieces are zeroed on the data.
+    // global k-step index over the concatenated segments; wave w takes k-steps w, w+DW, ...  U of them are resolved
+    // to (segment, k) and requested together, so a wave pays one memory round trip per U k-steps whatever the number
+    // of segments.  Every load is unconditional from a clamped (always valid) address; out-of-range pieces are
+    // zeroed on the data.
     const int rowc = row >= 0 ? row : 0;
-    int ks_base = 0;
-    for (int sidx = 0; sidx < a.ns; ++sidx) {
-        const Seg& sg = a.seg[sidx];
-        const int nks = (sg.K + 31) / 32, kmax = sg.K - 4;
-        const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
-        int first = (wave - ks_base % DW + DW) % DW;          // first local k-step of this wave in the segment
-        for (int ks = first; ks < nks; ks += 2 * DW) {
-            float4 bw[2][2], ax[2][NB][2];
-            bool okw[2][2];
+    int nks_s[3], cum[4];
+    cum[0] = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = (ks + DW * u) * 32 + fq * 8;
-                okw[u][0] = row >= 0 && k < sg.K;
-                okw[u][1] = row >= 0 && k + 4 < sg.K;
-                bw[u][0] = ldg4(wp + min(k, kmax));
-                bw[u][1] = ldg4(wp + min(k + 4, kmax));
+    for (int i = 0; i < 3; ++i) { nks_s[i] = i < a.ns ? (a.seg[i].K + 31) / 32 : 0; cum[i + 1] = cum[i] + nks_s[i]; }
+    const int total = cum[3];
+    constexpr int U = 3;
+    for (int g0 = wave; g0 < total; g0 += U * DW) {
+        float4 bw[U][2], ax[U][NB][2];
+        bool okw[U][2], oka[U][2];
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) {
-                    const int b = min(bt * 16 + fr, a.B - 1);
-                    const float* xp = sg.x + (long)b * sg.ldx;
-                    ax[u][bt][0] = ldg4(xp + min(k, kmax));
-                    ax[u][bt][1] = ldg4(xp + min(k + 4, kmax));
-                }
-            }
+        for (int u = 0; u < U; ++u) {
+            const int g = g0 + DW * u, gc = min(g, total - 1);
+            const int si = gc >= cum[2] ? 2 : (gc >= cum[1] ? 1 : 0);
+            const Seg& sg = a.seg[si];
+            const int k = (gc - cum[si]) * 32 + fq * 8, kmax = sg.K - 4;
+            const bool live = g < total;
+            oka[u][0] = live && k < sg.K;
+            oka[u][1] = live && k + 4 < sg.K;
+            okw[u][0] = oka[u][0] && row >= 0;
+            okw[u][1] = oka[u][1] && row >= 0;
+            const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
+            bw[u][0] = ldg4(wp + min(k, kmax));
+            bw[u][1] = ldg4(wp + min(k + 4, kmax));
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = (ks + DW * u) * 32 + fq * 8;
-                const bf16x8 bf = pack(sel4(okw[u][0], bw[u][0]), sel4(okw[u][1], bw[u][1]));
-#pragma unroll
-                for (int bt = 0; bt < NB; ++bt) {
-                    const bool okb = bt * 16 + fr < a.B;
-                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        pack(sel4(okb && k < sg.K, ax[u][bt][0]), sel4(okb && k + 4 < sg.K, ax[u][bt][1])), bf, acc[bt], 0, 0, 0);
-                }
+            for (int bt = 0; bt < NB; ++bt) {
+                const int b = min(bt * 16 + fr, a.B - 1);
+                const float* xp = sg.x + (long)b * sg.ldx;
+                ax[u][bt][0] = ldg4(xp + min(k, kmax));
+                ax[u][bt][1] = ldg4(xp + min(k + 4, kmax));
             }
         }
-        ks_base += nks;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bf16x8 bf = pack(sel4(okw[u][0], bw[u][0]), sel4(okw[u][1], bw[u][1]));
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                const bool okb = bt * 16 + fr < a.B;
+                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    pack(sel4(okb && oka[u][0], ax[u][bt][0]), sel4(okb && oka[u][1], ax[u][bt][1])), bf, acc[bt], 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    skinny_epilogue<NB, DW>(a, Gl, blk);
+    skinny_epilogue<NB, DW>(a, Gl, blk, pre0);
 }
 
 constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU

@@ -84,7 +84,8 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
                        f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
 
 
-PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_kernel', 'gemm': 'gemm_kernel<0, true, true'}
+PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_kernel', 'gemm': 'gemm_kernel<0, true, true',
+            'vgg_fwd': 'conv_fwd_kernel<0, 2, 0>', 'vgg_bwd': 'conv_wgrad_kernel'}
 
 
 def attach_pmc_traffic(roof, workload):
@@ -183,9 +184,16 @@ def main():
 
     note(f'{dt * 1e3 / a.steps:.1f} ms/step; kernel timing pass')
     # ---- roofline of the dominant kernel: live HIP-event timing of its launches over 3 more steps
-    run(a.warmup + a.steps, 1, known_lengths=True)          # let the host run ahead of the GPU
+    # The brackets are HIP events on the launch stream, so a bracket also counts any time the GPU waits for the host
+    # to enqueue the next kernel.  Each timed step therefore starts with a ~25 ms device-side sleep: the host (≈14 ms
+    # of enqueue work per step) gets a full step ahead and the brackets see back-to-back kernels, as in the timed
+    # loop above and in the rocprofv3 trace.
+    run(a.warmup + a.steps, 1, known_lengths=True)
     prof = ops.enable_kernel_timing()
-    run(a.warmup + a.steps + 1, 3, known_lengths=True)
+    for i in range(3):
+        if hasattr(torch.cuda, '_sleep'):
+            torch.cuda._sleep(50_000_000)
+        run(a.warmup + a.steps + 1 + i, 1, known_lengths=True)
     torch.cuda.synchronize()
     roof = ops.kernel_timing_summary(prof)
     ops.disable_kernel_timing()

@@ -214,3 +214,35 @@ def test_trainer_trace_losses():
         st.step(best[1], best[2])
     for k, v in st.W.items():
         close(v, d['w_after.' + k], atol=2e-5)
+
+
+def test_ctc_prefix_scores():
+    """CTCPrefixScore.init_state / cheap_compute (ctc.py:19-27,65-101) incl. the repeated-token case."""
+    from oracle import beam_ref as Bm
+    d = G('g5_ctc_prefix.npz')
+    lp = d['lp'][0]
+    r0 = Bm.ctc_prefix_init(lp)
+    close(r0, d['r0'], atol=1e-5)
+    cand = [1, 2, 3, 4, 5]
+    psi1, r1 = Bm.ctc_prefix_cheap(lp, [], r0, cand)
+    close(psi1, d['psi1'], atol=1e-5); close(r1, d['r1'], atol=1e-5)
+    psi2, r2 = Bm.ctc_prefix_cheap(lp, [3], r1[cand.index(3)], cand)
+    close(psi2, d['psi2'], atol=1e-5); close(r2, d['r2'], atol=1e-5)
+    psi3, r3 = Bm.ctc_prefix_cheap(lp, [3, 3], r2[cand.index(3)], [2, 3, 5])
+    close(psi3, d['psi3'], atol=1e-5); close(r3, d['r3'], atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['loc_ctc_b1', 'loc_ctc_b3', 'dot_att_b1', 'dot_att_b3'])
+def test_beam_decode(name):
+    """Seq2Seq.beam_decode (asr.py:155-258): same hypotheses in the same order, per-token scores within 2e-5."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tools'))
+    from gen_golden import TINY
+    from oracle import beam_ref as Bm
+    d = G(f'g6_beam_{name}.npz')
+    cfg = R.parse_cfg(TINY[name.rsplit('_', 1)[0]])
+    hyps = Bm.beam_decode(W_of(d), cfg, torch.tensor(d['x']), int(d['steps']), int(d['beam']))
+    assert len(hyps) == int(d['n_hyps'])
+    for i, (seq, scores) in enumerate(hyps):
+        assert seq == d[f'hyp{i}.seq'].tolist(), (i, seq)
+        close(np.array(scores), d[f'hyp{i}.scores'], atol=2e-5)

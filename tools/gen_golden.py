@@ -427,9 +427,38 @@ def g5_prefix(out):
              psi3=psi3, r3=r3)
 
 
+# ----------------------------------------------------------------------------- G6 beam search
+def g6_beam(asr, out):
+    """Seq2Seq.beam_decode (asr.py:155-258) on one utterance: joint CTC/attention (loc, 2 decoder layers) and
+    attention-only (dot), beam 1 and 3; every returned hypothesis with its token ids and per-token scores."""
+    for name in ['loc_ctc', 'dot_att']:
+        cfg = TINY[name]
+        for beam in [1, 3]:
+            _seed(61)
+            gen = torch.Generator().manual_seed(17)
+            V, T, D, steps = 9, 23, 5, 7
+            x = _ragged_x(1, T, D, [T], gen)
+            model = asr.Seq2Seq(x, V, cfg)
+            with torch.no_grad():                       # sharpen the random-init output layer: distinct beams
+                model.char_trans.weight.mul_(6.0)
+                if cfg['optimizer']['joint_ctc'] > 0:
+                    model.ctc_layer.weight.mul_(4.0)
+            model.eval()
+            model.decode_lm_weight = 0
+            with torch.no_grad():
+                hyps = model.beam_decode(x, steps, [T], beam)
+            d = {'x': _np(x), 'V': np.array(V), 'steps': np.array(steps), 'beam': np.array(beam), 'n_hyps': np.array(len(hyps))}
+            for i, h in enumerate(hyps):
+                d[f'hyp{i}.seq'] = np.array(h.outIndex, dtype=np.int64)
+                d[f'hyp{i}.scores'] = np.array([float(v) for v in h.output_scores], dtype=np.float64)
+            d.update(_state(model, 'w.'))
+            np.savez(os.path.join(out, f'g6_beam_{name}_b{beam}.npz'), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
+    ap.add_argument('--only', default='', help='comma list of groups to (re)generate, e.g. g6; default all')
     a = ap.parse_args()
     out = os.path.abspath(a.out)
     os.makedirs(out, exist_ok=True)
@@ -437,15 +466,24 @@ def main():
     Writer = _install_shims()
     sys.path.insert(0, REF)
     import src.asr as asr
-    g1_rnnlayer(asr, out)
-    g1_listener(asr, out)
-    g1_attention(asr, out)
-    g1_vgg(asr, out)
-    g1_speller(asr, out)
-    g2_ctc(out)
-    g3_steps(asr, out)
-    g4_trace(Writer, out)
-    g5_prefix(out)
+    only = set(v for v in a.only.split(',') if v)
+    want = lambda g: not only or g in only
+    if want('g1'):
+        g1_rnnlayer(asr, out)
+        g1_listener(asr, out)
+        g1_attention(asr, out)
+        g1_vgg(asr, out)
+        g1_speller(asr, out)
+    if want('g2'):
+        g2_ctc(out)
+    if want('g3'):
+        g3_steps(asr, out)
+    if want('g4'):
+        g4_trace(Writer, out)
+    if want('g5'):
+        g5_prefix(out)
+    if want('g6'):
+        g6_beam(asr, out)
     tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
     print('wrote', len(os.listdir(out)), 'files,', tot // 1024, 'KiB ->', out)
 

@@ -5,7 +5,7 @@ Attention and Speller, so checkpoints and the Trainer code carry over; every ten
 All parameters (and their gradients) are views of one flat fp32 buffer each, which the fused optimiser and the
 RCCL gradient all-reduce treat as a single vector.
 
-Not built here (out of scope / next rows): beam_decode + CTC prefix scorer (N3), multi-head attention (broken in the reference, asr.py:436), GRU cells, dropout > 0.
+Not built here (out of scope): multi-head attention (broken in the reference, asr.py:436), GRU cells, dropout > 0.
 """
 import math
 import random
@@ -223,6 +223,12 @@ class Seq2Seq(nn.Module):
                 lens_dev = torch.div(lens_dev, sr, rounding_mode='floor').to(torch.int32)
             h = ops.linear(h, self.P(f'encoder.proj{l}.weight'), self.P(f'encoder.proj{l}.bias'), act=1)
         return ops.Transpose01Fn.apply(h), lens_dev, lens_host
+
+    # -- decoding --------------------------------------------------------------------------------------------
+    def beam_decode(self, audio_feature, decode_step, state_len, decode_beam_size):
+        """reference asr.py:155-258: top-N hypotheses of one utterance, joint CTC/attention scoring."""
+        from .beam import beam_decode
+        return beam_decode(self, audio_feature, decode_step, state_len, decode_beam_size)
 
     # -- full forward ----------------------------------------------------------------------------------------
     def forward(self, audio_feature, decode_step, tf_rate=0.0, teacher=None, state_len=None):

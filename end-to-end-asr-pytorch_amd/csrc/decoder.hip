@@ -257,9 +257,10 @@ int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 
 }  // namespace
 
-extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
-                               const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode,
-                               unsigned seed, las_dec_state* st_, void* stream) {
+// resume: one step (L = 1) from caller-provided states (slot 0 of hs/cs, att[0], tok[0..B)), see las_decoder_step
+static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                       const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode, unsigned seed,
+                       las_dec_state* st_, void* stream, bool resume) {
     LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_);
     const int B = d->B, Tp = d->Tp, E = d->E, A = d->A, C = d->C, NL = d->NL, V = d->V, L = d->L, loc = d->loc, prec = d->prec;
     LAS_CHECK_ARG(B > 0 && Tp > 0 && E > 0 && A > 0 && C > 0 && NL >= 1 && NL <= 4 && L >= 0 && V > 1);
@@ -274,11 +275,11 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
     LAS_CHECK_ARG(all_teacher || (p->w_char && p->b_char && s.logits_step));
     const long XI = C + E, BC = (long)B * C;
     // zero initial states (reference asr.py:338-340)
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 0; l < NL && !resume; ++l) {
         LAS_HIP(hipMemsetAsync(s.hs + (long)l * (L + 1) * BC, 0, sizeof(float) * BC, st));
         LAS_HIP(hipMemsetAsync(s.cs + (long)l * (L + 1) * BC, 0, sizeof(float) * BC, st));
     }
-    if (loc) { hipLaunchKernelGGL(uniform_att_kernel, dim3(B), dim3(256), 0, st, enc_len, Tp, s.att); LAS_LAUNCH_OK(); }
+    if (loc && !resume) { hipLaunchKernelGGL(uniform_att_kernel, dim3(B), dim3(256), 0, st, enc_len, Tp, s.att); LAS_LAUNCH_OK(); }
     // embeddings of the teacher tokens for every step (step 0 feeds y[:,0] = <sos>)
     if (y) {
         hipLaunchKernelGGL(embed_rows_kernel, dim3(L * B), dim3(256), 0, st, p->emb, (const long long*)y, Ly, nullptr, B, C, V,
@@ -334,8 +335,8 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
                                xin_t, XI, nullptr);
             LAS_LAUNCH_OK();
         } else if (t == 0 && !y) {
-            // no teacher at all: <sos> = 0
-            LAS_HIP(hipMemsetAsync(s.tok, 0, sizeof(int32_t) * B, st));
+            // no teacher at all: <sos> = 0 (or, resuming, the caller's tokens)
+            if (!resume) LAS_HIP(hipMemsetAsync(s.tok, 0, sizeof(int32_t) * B, st));
             hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, st, p->emb, nullptr, 0, s.tok, B, C, V, xin_t, XI, nullptr);
             LAS_LAUNCH_OK();
         }
@@ -352,4 +353,23 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
         }
     }
     return LAS_OK;
+}
+
+extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                               const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode,
+                               unsigned seed, las_dec_state* st_, void* stream) {
+    return decoder_run(d, p, enc, psi, enc_len, y, Ly, step_mode, seed, st_, stream, false);
+}
+
+extern "C" int las_decoder_step(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                                const int32_t* enc_len, las_dec_state* st_, float* logits, void* stream) {
+    LAS_CHECK_ARG(d && p && st_ && logits && d->L == 1 && p->w_char && p->b_char && st_->tok);
+    static const uint8_t teacher_none = 2;                  // no teacher tensor: step 0 feeds state->tok
+    int rc = decoder_run(d, p, enc, psi, enc_len, nullptr, 0, &teacher_none, 0, st_, stream, true);
+    if (rc) return rc;
+    const long BC = (long)d->B * d->C;
+    const float* htop = st_->hs + ((long)(d->NL - 1) * 2 + 1) * BC;
+    return las_skinny_launch(d->prec, htop, d->C, p->w_char, d->C, d->C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0,
+                             d->B, d->V, p->b_char, nullptr, 0, logits, d->V, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                             (hipStream_t)stream);
 }

@@ -287,9 +287,101 @@ class Trainer(Solver):
 
 
 class Tester(Solver):
+    """Handler for the complete inference progress; reference src/solver.py:293-441.  Beam search keeps the
+    reference's batch size of 1 utterance, but every hypothesis of the beam (and every CTC candidate) advances in one
+    batched device step (beam.py), so --njobs is accepted and unused."""
+
     def __init__(self, config, paras):
-        raise NotImplementedError('beam-search decoding (Tester, src/solver.py:294-441) is outside the training hot path '
-                                  '(SURVEY.md §8f N3)')
+        super().__init__(config, paras)
+        self.verbose('During beam decoding, batch size is set to 1 (the beam is batched on the device).')
+        self.njobs = getattr(paras, 'njobs', 1)
+        s = config['solver']
+        self.decode_step_ratio = s['max_decode_step_ratio']
+        self.decode_beam_size = s['decode_beam_size']
+        self.decode_file = '_'.join(['decode', 'beam', str(s['decode_beam_size']), 'len', str(s['max_decode_step_ratio'])])
+        self.log = None
+        self.step = 0
+        self.best_val_ed = -1.0                      # never overwrite the checkpoint from the Tester's dev check
+
+    def write_log(self, name, d):
+        self.verbose('{}: {}'.format(name, {k: round(float(v), 4) for k, v in d.items()}))
+
+    def load_data(self):
+        self.verbose('Loading testing data ' + str(self.config['solver']['test_set']) + ' from ' +
+                     str(self.config['solver'].get('data_path')))
+        kw = dict(self.config['solver'])
+        self.test_set = LoadDataset('test', text_only=False, use_gpu=self.paras.gpu, **kw)
+        self.dev_set = LoadDataset('dev', text_only=False, use_gpu=self.paras.gpu, **kw)
+        for self.sample_x, _ in self.test_set:
+            break
+        if len(self.sample_x.shape) == 4:
+            self.sample_x = self.sample_x[0]
+
+    def set_model(self):
+        """Load the saved ASR (state_dict checkpoint written by Trainer.save_checkpoint)."""
+        path = os.path.join(self.ckpdir, 'asr')
+        self.verbose('Load ASR model from ' + path)
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        mp = json.loads(ck['config']) if 'config' in ck else self.config['asr_model']
+        self.asr_model = Seq2Seq(self.sample_x, self.mapper.get_dim(), mp, device=self.device)
+        self.asr_model.load_reference_state(ck['model'])
+        self.ctc_weight = mp['optimizer']['joint_ctc']
+        s = self.config['solver']
+        dcw = s.get('decode_ctc_weight', 0)
+        if dcw > 0:                                   # solver.py:317-323
+            assert self.asr_model.joint_ctc, 'The ASR was not trained with CTC'
+            self.verbose('Joint CTC decoding is enabled with weight = ' + str(dcw))
+            self.decode_file += '_ctc{:}'.format(dcw)
+            self.asr_model.ctc_weight = dcw
+        self.asr_model.joint_ctc = dcw > 0
+        if s.get('decode_lm_weight', 0) > 0:
+            raise NotImplementedError('RNN-LM fusion (solver.py:326-333) is outside the LAS path (SURVEY.md §2.1)')
+        self.asr_model.decode_lm_weight = 0
+        self.asr_model.eval()
+        self.verbose('Checking models performance on dev set ' + str(s['dev_set']) + '...')
+        self.valid()
+
+    valid = Trainer.valid                             # greedy attention decoding on the dev set (solver.py:389-441)
+
+    def save_checkpoint(self, path):                  # the Tester never saves
+        pass
+
+    def exec(self):
+        """Beam-search inference over the test set, solver.py:342-355."""
+        self.verbose('Start decoding with beam search, beam size = ' + str(self.decode_beam_size))
+        self.verbose('Number of utts to decode : {}'.format(len(self.test_set)))
+        n = 0
+        for x, y in self.test_set:
+            if len(x.shape) == 4:
+                x = x.squeeze(0)
+            if len(y.shape) == 3:
+                y = y.squeeze(0)
+            for b in range(x.shape[0]):
+                self.beam_decode(x[b:b + 1], y[b].tolist())
+                n += 1
+        self.verbose('Decode done, best results at {}.'.format(os.path.join(self.ckpdir, self.decode_file + '.txt')))
+        self.verbose('Top {} results at {}.'.format(self.decode_beam_size,
+                                                    os.path.join(self.ckpdir, self.decode_file + '_nbest.txt')))
+        return n
+
+    def write_hyp(self, hyps, y):
+        """Record decoding results, solver.py:357-369."""
+        gt = self.mapper.translate(y, return_string=True)
+        with open(os.path.join(self.ckpdir, self.decode_file + '.txt'), 'a') as f:
+            f.write(gt + '\t' + self.mapper.translate(hyps[0].outIndex, return_string=True) + '\n')
+        with open(os.path.join(self.ckpdir, self.decode_file + '_nbest.txt'), 'a') as f:
+            for hyp in hyps:
+                f.write(gt + '\t' + self.mapper.translate(hyp.outIndex, return_string=True) + '\n')
+
+    def beam_decode(self, x, y):
+        """solver.py:372-390."""
+        x = x.to(device=self.device, dtype=torch.float32)
+        state_len = ops.infer_lengths(x).cpu().tolist()
+        x = x[:, :max(state_len)].contiguous() if not self.asr_model.vgg else x
+        max_decode_step = int(math.ceil(state_len[0] * self.decode_step_ratio))
+        hyps = self.asr_model.beam_decode(x, max_decode_step, state_len, self.decode_beam_size)
+        self.write_hyp(hyps, y)
+        return hyps
 
 
 class RNNLM_Trainer(Solver):

@@ -241,6 +241,32 @@ int las_vgg_fwd(int prec, const float* x, int B, int T, int D, const las_vgg_par
 int las_vgg_bwd(int prec, const float* x, const float* dout, int B, int T, int D, int time_major,
                 const las_vgg_state* state, const las_vgg_grads* grads, float* dx, void* stream);
 
+/* ---- joint CTC/attention beam search (decode path) ----------------------------------------------
+ * One decode step for B hypotheses that resume from caller-provided states (Seq2Seq.beam_decode's inner loop,
+ * src/asr.py:205-215): dims->L must be 1; state slabs are those of las_decoder_fwd with L = 1, of which the
+ * caller fills slot 0 of hs/cs ([NL][2][B][C]), att[0] ([B][Tp], previous attention; loc only) and tok[0..B)
+ * (token fed at this step).  Writes slot 1 of hs/cs, att[1], xin, q, gates and logits [B][V] = char_trans(h_top)
+ * (asr.py:214).  enc/psi are per-hypothesis ([B][Tp][.]): replicate the utterance's encoding B times. */
+int las_decoder_step(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,
+                     const int32_t* enc_len, las_dec_state* state, float* logits, void* stream);
+/* out[r][:] = log_softmax(x[r][:])  (F.log_softmax at asr.py:181,215) */
+int las_log_softmax_rows(const float* x, int R, int V, float* out, void* stream);
+/* k largest entries of every row, descending, ties to the lower index (tensor.topk at asr.py:219,237); V*4 B <= 60 KB */
+int las_topk_rows(const float* x, int R, int V, int k, float* vals, int32_t* idx, void* stream);
+/* CTCPrefixScore (src/ctc.py): lp [T][V] log-probs of one utterance (blank = 0).  init: r0 [T][2] (ctc.py:19-27).
+ * score = cheap_compute (ctc.py:65-101) for N hypotheses x K candidates at once: r_prev [N][T][2], last_tok /
+ * prefix_len [N] (last_tok ignored when prefix_len = 0), cand [N][K] -> psi [N][K], r_out [N][K][T][2].
+ * float32 arithmetic with numpy's logaddexp, and the reference's treatment of cand == last_tok (it drops the
+ * blank-ending path of the prefix) kept as is. */
+int las_ctc_prefix_init(const float* lp, int T, int V, float* r0, void* stream);
+int las_ctc_prefix_score(const float* lp, int T, int V, const float* r_prev, const int32_t* last_tok,
+                         const int32_t* prefix_len, const int32_t* cand, int N, int K, float* psi, float* r_out,
+                         void* stream);
+/* cur [N][V] (in place) = (1-w)*cur + w*hack, hack = -1e6 except hack[cand[n][j]] = psi[n][j] - prev_ctc[n];
+ * then cur[n][0] = -1e7 (asr.py:218-229) */
+int las_beam_combine(float* cur, int N, int V, const int32_t* cand, const float* psi, const float* prev_ctc, int K,
+                     float ctc_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,10 @@ def beam_decode(model, audio_feature, decode_step, state_len, decode_beam_size):
             check(L_.las_log_softmax_rows(ptr(logit), I(Tp), I(V), ptr(lp), cur_stream()), 'las_log_softmax_rows')
             r_prev = torch.empty(1, Tp, 2, **f32)
             check(L_.las_ctc_prefix_init(ptr(lp), I(Tp), I(V), ptr(r_prev), cur_stream()), 'las_ctc_prefix_init')
+        # the utterance's encoding, replicated once for the widest beam (the step kernels index enc/psi per hypothesis)
+        encB = enc.expand(beam, Tp, E).contiguous()
+        psiB = psi.expand(beam, Tp, A).contiguous()
+        lenB = enc_len_dev.expand(beam).contiguous()
         # device state of the live hypotheses (row = hypothesis)
         h = torch.zeros(NL, 1, C, **f32)
         c = torch.zeros(NL, 1, C, **f32)
@@ -105,11 +109,8 @@ def beam_decode(model, audio_feature, decode_step, state_len, decode_beam_size):
             st = DecState()
             for k, v in S.items():
                 setattr(st, k, v.data_ptr())
-            encN = enc.expand(N, Tp, E).contiguous()
-            psiN = psi.expand(N, Tp, A).contiguous()
-            lenN = enc_len_dev.expand(N).contiguous()
             logits = torch.empty(N, V, **f32)
-            check(L_.las_decoder_step(ctypes.byref(d), ctypes.byref(params), ptr(encN), ptr(psiN), ptr(lenN), ctypes.byref(st),
+            check(L_.las_decoder_step(ctypes.byref(d), ctypes.byref(params), ptr(encB), ptr(psiB), ptr(lenB), ctypes.byref(st),
                                       ptr(logits), cur_stream()), 'las_decoder_step')
             cur = torch.empty_like(logits)
             check(L_.las_log_softmax_rows(ptr(logits), I(N), I(V), ptr(cur), cur_stream()), 'las_log_softmax_rows')
@@ -128,8 +129,11 @@ def beam_decode(model, audio_feature, decode_step, state_len, decode_beam_size):
             topi = torch.empty(N, kb, **i32)
             check(L_.las_topk_rows(ptr(cur), I(N), I(V), I(kb), ptr(topv), ptr(topi), cur_stream()), 'las_topk_rows')
             # ---- host bookkeeping on N x beam numbers (Hypothesis.addTopk, postprocess.py:71-104)
-            topv_h, topi_h = topv.cpu().tolist(), topi.cpu().tolist()
-            cand_h = cand.cpu().tolist() if joint_ctc else None
+            pack = [topv, topi.float()] + ([cand.float()] if joint_ctc else [])       # one D2H (ids < 2^24 are exact in fp32)
+            host = torch.cat(pack, dim=1).cpu()
+            topv_h = host[:, :kb].tolist()
+            topi_h = host[:, kb:2 * kb].to(torch.int64).tolist()
+            cand_h = host[:, 2 * kb:].to(torch.int64).tolist() if joint_ctc else None
             nxt = []
             for hyp in live:
                 n = hyp.slot

@@ -8,13 +8,13 @@ namespace {
 
 constexpr float LOGZERO = -100000000.0f;            // ctc.py:11
 
-// numpy's float32 logaddexp (npy_logaddexpf)
+// float32 logaddexp as numpy's npy_logaddexpf (max + log1p(exp(-|d|))), on the hardware exp2/log2 units: the T'-long
+// chain of a (hypothesis, candidate) pair is three of these per frame, strictly sequential, so their latency IS the
+// kernel time.  log(1 + e) instead of log1p(e) differs by < 6e-8 absolute (e < 1), far below the float32 resolution of
+// the log-probabilities being summed.
 __device__ __forceinline__ float logaddexp_np(float x, float y) {
-    if (x == y) return x + 0.693147180559945309417232121458176568f;
-    const float d = x - y;
-    if (d > 0.f) return x + log1pf(expf(-d));
-    if (d <= 0.f) return y + log1pf(expf(d));
-    return d;                                        // NaN
+    const float m = fmaxf(x, y), d = -fabsf(x - y);
+    return m + __logf(1.f + __expf(d));
 }
 
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int V, float* __restrict__ out) {
@@ -93,15 +93,31 @@ __global__ __launch_bounds__(64) void ctc_prefix_score_kernel(const float* __res
     float rn = LOGZERO, rb = LOGZERO;                // r[start-1][0], r[start-1][1]
     if (len == 0) { rn = lp[c]; ro[0] = rn; }        // empty prefix: r[0][0] = x[0][c]  (start = 1)
     float p = rn;                                    // psi = r[start-1][0]
-    for (int t = start; t < T; ++t) {
-        const float pb = c == lc ? LOGZERO : rp[2 * (t - 1) + 1];
-        const float phi = logaddexp_np(rp[2 * (t - 1)], pb);
-        const float x = lp[(long)t * V + c];
-        const float nn = logaddexp_np(rn, phi) + x;
-        const float nb = logaddexp_np(rb, rn) + lp[(long)t * V];
-        p = logaddexp_np(p, phi + x);
-        rn = nn; rb = nb;
-        ro[2 * t] = nn; ro[2 * t + 1] = nb;
+    // the operands of the recurrence (r_prev, lp) do not depend on it: 8 frames are requested together, then consumed
+    constexpr int U = 8;
+    for (int t0 = start; t0 < T; t0 += U) {
+        float2 rv[U];
+        float xc[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(t0 + u, T - 1);
+            rv[u] = *(const float2*)(rp + 2 * (t - 1));
+            xc[u] = lp[(long)t * V + c];
+            xb[u] = lp[(long)t * V];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                const float pb = c == lc ? LOGZERO : rv[u].y;
+                const float phi = logaddexp_np(rv[u].x, pb);
+                const float nn = logaddexp_np(rn, phi) + xc[u];
+                const float nb = logaddexp_np(rb, rn) + xb[u];
+                p = logaddexp_np(p, phi + xc[u]);
+                rn = nn; rb = nb;
+                *(float2*)(ro + 2 * t) = make_float2(nn, nb);
+            }
+        }
     }
     psi[pair] = p;
 }

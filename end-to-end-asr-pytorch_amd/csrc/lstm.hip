@@ -32,10 +32,12 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr size_t MIN_LDS = 84 * 1024;            // > 80 KiB: at most one workgroup per CU
 
 constexpr int MAX_SLICES = 16;
+constexpr int CNT_STRIDE = 64;      // words: every counter on a 256-byte line of its own (pollers of one (direction, slice)
+                                    // group must not share a line with another group's atomics)
 struct SyncWords {          // zeroed by hipMemsetAsync before every launch
-    unsigned cnt[2 * MAX_SLICES];   // arrivals per (direction, batch slice)
+    unsigned cnt[2 * MAX_SLICES * CNT_STRIDE];   // arrivals per (direction, batch slice)
     unsigned abort_;                // set on spin timeout
-    unsigned pad[3];
+    unsigned pad[63];
 };
 
 // one-v_exp activations for the cell pointwise (abs err ~1e-7; the recurrence is fp32 throughout)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * 4 * H;
-    unsigned* cnt = &sync->cnt[d * MAX_SLICES + bs];
+    unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? s : a.T - 1 - s;
@@ -244,16 +246,21 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
             __syncthreads();
             // (d) gate pre-activations: wave w <-> gate w
             if constexpr (KS > 0) {               // weights from registers, h from LDS
+                // every fragment is requested before the first MFMA (unconditionally: a k-step beyond Kp re-reads the
+                // last one against a zero weight fragment); issued one by one behind a branch each, the ten
+                // ds_read -> mfma pairs of a wave took 1 460 cycles per step, all of it LDS latency (now 570)
                 const int lane_ = threadIdx.x & 63;
+                bf16x8 av[KS][NB];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    if (ks * 32 < Kp) {
 #pragma unroll
-                        for (int bt = 0; bt < NB; ++bt) {
-                            const bf16x8 av = *(const bf16x8*)((const bf16_t*)Hl + (bt * 16 + (lane_ & 15)) * ld + ks * 32 + (lane_ >> 4) * 8);
-                            acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wfrag[ks], acc[bt], 0, 0, 0);
-                        }
-                    }
+                    for (int bt = 0; bt < NB; ++bt)
+                        av[ks][bt] = *(const bf16x8*)((const bf16_t*)Hl + (bt * 16 + (lane_ & 15)) * ld + min(ks * 32, Kp - 32) + (lane_ >> 4) * 8);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt)
+                        acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ks][bt], wfrag[ks], acc[bt], 0, 0, 0);
             } else {
                 if (!(a.dbg & 4)) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
             }
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * K4, NDH = ND * H;
-    unsigned* cnt = &sync->cnt[d * MAX_SLICES + bs];
+    unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
     const int kq = KC / KSTEP / 4;                        // k-steps per wave per chunk
 
     for (int s = 0; s < a.T; ++s) {
@@ -527,7 +534,7 @@ extern "C" void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int
     *T_out = a.T_out; *F_out = a.F_out;
 }
 
-extern "C" size_t las_lstm_sync_bytes(void) { return 256; }
+extern "C" size_t las_lstm_sync_bytes(void) { return sizeof(SyncWords); }
 
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                                 const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
@@ -550,7 +557,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
-    LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
         // register-resident operands for the common hidden sizes and small batch slices (VGPR budget: KS*4*(1+NB))
@@ -586,7 +593,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     size_t lds = bwd_lds(prec, H, NB, NC);
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
-    LAS_HIP(hipMemsetAsync(sync, 0, 256, st));
+    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
 #define LAS_BWD_ARGS a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
         const int kq = K4p / 32 / 4;                        // k-steps per wave

@@ -463,6 +463,231 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, K-split
+// Same ownership as above, but the recurrent product is split over K instead of N: workgroup g multiplies ITS OWN
+// dgates_t [Bs x 64] (4 gates x 16 units, just produced by its pointwise pass, still in LDS) by its 64 rows of W_hh
+// and gets a partial dh_{t-1} for ALL H columns; the 16-column piece of consumer c goes to c's inbox, and c sums the
+// G pieces it receives.  The exchange is a reduce-scatter of [Bs x H] (as large as the forward's all-gather of h)
+// instead of an all-gather of dgates [Bs x 4H]: 7.7 KB instead of 30 KB pulled per workgroup and step at H = 320,
+// and nothing has to be fetched before the MFMAs.  Partial sums travel as bf16 pairs (rows 2r, 2r+1 of one column)
+// in bf16 mode, as f32 in f32 mode.  The inboxes are a ring of 4 steps (a producer can be at most one step ahead of
+// the slowest reader of its group); hand-off protocol as in the forward kernel.
+constexpr int KS_SLOTS = 4;
+__host__ __device__ inline int ks_words_per_tile(int prec, int NB) { return NB * 16 * (prec == LAS_PREC_BF16 ? 8 : 16); }
+
+template <int PREC, int NB, int MT>     // MT = tiles (consumers) per wave = ceil(G / 4)
+__global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float* __restrict__ dy,
+                                                         const float* __restrict__ gates, const float* __restrict__ cs,
+                                                         const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
+                                                         unsigned* __restrict__ pex, float* __restrict__ dgf,
+                                                         SyncWords* sync, int* status) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    constexpr int KO = 64, LDK = KO + VEC;                // own dgates: k = gate*16 + unit
+    constexpr int WPR = PREC == LAS_PREC_BF16 ? 8 : 16;   // exchange words per batch row of a 16-column piece
+    constexpr int WPT = NB * 16 * WPR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, B = a.B, ND = a.ND, K4 = 4 * H, G = a.G;
+    const int d = blockIdx.x / (G * a.NS), g = (blockIdx.x % (G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * 16;
+    const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
+    T* Wl = (T*)smem;                                     // [G*16][LDK]  W_hh[my 64 gate rows][every column], k contiguous
+    T* Dl = Wl + (size_t)G * 16 * LDK;                    // [NB*16][LDK] my dgates of this step
+    unsigned* Pl = (unsigned*)(Dl + NB * 16 * LDK);       // [G][WPT] inbox of the previous step
+    int* lensl = (int*)(Pl + (size_t)G * WPT);
+    int* flag = lensl + NB * 16;
+
+    for (int i = threadIdx.x; i < G * 16 * KO; i += NT) {
+        const int col = i % (G * 16), k = i / (G * 16), gi = k >> 4, n = k & 15;
+        float v = 0.f;
+        if (col < H && j0 + n < H) v = w_hh[((long)d * K4 + gi * H + j0 + n) * H + col];
+        Wl[col * LDK + k] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
+    }
+    for (int i = threadIdx.x; i < NB * 16 * LDK; i += NT) Dl[i] = (T)0;
+    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    // The product is taken transposed (A = W rows = output columns, B = dgates rows = batch), so a lane ends up with
+    // FOUR CONSECUTIVE output columns of one batch row: one 8-byte (bf16) / 16-byte (f32) store per tile.
+    // bf16: the weight fragments of this wave's tiles stay in registers for all T steps.
+    bf16x8 wfrag[PREC == LAS_PREC_BF16 ? MT : 1][2];
+    if constexpr (PREC == LAS_PREC_BF16) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int c = min(wave + 4 * i, G - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wfrag[i][ks] = *(const bf16x8*)((const bf16_t*)Wl + (c * 16 + fr) * LDK + ks * 32 + fq * 8);
+        }
+    }
+
+    // pointwise elements of this thread: the pair (row eb, units en, en+1)  (NB <= 2: at most one pair per thread)
+    const int e = threadIdx.x, eb = e >> 3, en = (e & 7) * 2, j = j0 + en;
+    const bool ev = e < NB * 16 * 8 && eb < Bl && j < H;
+    float dc_carry[2] = {0.f, 0.f};
+    const int ND4H = ND * K4, NDH = ND * H;
+    unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
+    const long slot_words = (long)ND * a.NS * G * G * WPT;
+    auto inbox = [&](int slot, int consumer, int producer) -> unsigned* {
+        return pex + slot * slot_words + ((((long)d * a.NS + bs) * G + consumer) * G + producer) * WPT;
+    };
+    // saved activations / incoming gradient of one step, requested a step ahead of their use
+    float2 sg[4], sc, scp, sdy;
+    auto load_inputs = [&](int s) {
+        const int t = d == 0 ? a.T - 1 - s : s, tp = d == 0 ? t - 1 : t + 1;
+        sc = scp = sdy = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) sg[gi] = make_float2(0.f, 0.f);
+        if (!ev || s >= a.T || t >= lensl[eb]) return;
+        const int b = b0 + eb;
+        const long ro = (long)t * B + b;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) sg[gi] = *(const float2*)(gates + ro * ND4H + d * K4 + gi * H + j);
+        sc = *(const float2*)(cs + ro * NDH + d * H + j);
+        if (tp >= 0 && tp < lensl[eb]) scp = *(const float2*)(cs + ((long)tp * B + b) * NDH + d * H + j);
+        bool ok;
+        const long yo = y_offset(a, t, b, d, j, ok);
+        if (ok) sdy = *(const float2*)(dy + yo);
+    };
+    load_inputs(0);
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = d == 0 ? a.T - 1 - s : s;           // reverse of the forward processing order
+        float dh_rec[2] = {0.f, 0.f};
+        if (s > 0) {
+            if (!block_wait(cnt, (unsigned)G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, WPT, WPT, 0, Pl, WPT);
+            __syncthreads();
+            if (ev) {                                     // sum of the G pieces, four independent chains
+                float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+                const unsigned* pw = Pl + eb * WPR + (PREC == LAS_PREC_BF16 ? en / 2 : en);
+                int p = 0;
+                for (; p + 3 < G; p += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if constexpr (PREC == LAS_PREC_BF16) {
+                            const unsigned w = pw[(p + u) * WPT];
+                            s0[u] += __uint_as_float(w << 16);
+                            s1[u] += __uint_as_float(w & 0xffff0000u);
+                        } else {
+                            const uint2 w = *(const uint2*)(pw + (p + u) * WPT);
+                            s0[u] += __uint_as_float(w.x);
+                            s1[u] += __uint_as_float(w.y);
+                        }
+                    }
+                }
+                for (; p < G; ++p) {
+                    if constexpr (PREC == LAS_PREC_BF16) {
+                        const unsigned w = pw[p * WPT];
+                        s0[0] += __uint_as_float(w << 16);
+                        s1[0] += __uint_as_float(w & 0xffff0000u);
+                    } else {
+                        const uint2 w = *(const uint2*)(pw + p * WPT);
+                        s0[0] += __uint_as_float(w.x);
+                        s1[0] += __uint_as_float(w.y);
+                    }
+                }
+                dh_rec[0] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+                dh_rec[1] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+            }
+        }
+        // pointwise BPTT -> my dgates of this step, into LDS for the product below
+        float dg[4][2];
+        {
+            const bool m = ev && t < lensl[min(eb, NB * 16 - 1)];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float ig = q ? sg[0].y : sg[0].x, fg = q ? sg[1].y : sg[1].x;
+                const float gg = q ? sg[2].y : sg[2].x, og = q ? sg[3].y : sg[3].x;
+                const float ct = q ? sc.y : sc.x, cp = q ? scp.y : scp.x;
+                const float dh = (q ? sdy.y : sdy.x) + dh_rec[q];
+                const float tc = ftanh(ct);
+                const float dc = dh * og * (1.f - tc * tc) + dc_carry[q];
+                const bool mq = m && (j + q < H);
+                dg[0][q] = mq ? dc * gg * ig * (1.f - ig) : 0.f;
+                dg[1][q] = mq ? dc * cp * fg * (1.f - fg) : 0.f;
+                dg[2][q] = mq ? dc * ig * (1.f - gg * gg) : 0.f;
+                dg[3][q] = mq ? dh * tc * og * (1.f - og) : 0.f;
+                dc_carry[q] = mq ? dc * fg : 0.f;
+            }
+            if (ev) {
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    if constexpr (PREC == LAS_PREC_BF16) *(unsigned*)(Dl + eb * LDK + gi * 16 + en) = pack_bf16x2(dg[gi][0], dg[gi][1]);
+                    else *(float2*)(Dl + eb * LDK + gi * 16 + en) = make_float2(dg[gi][0], dg[gi][1]);
+                }
+            }
+        }
+        __syncthreads();
+        if (s + 1 < a.T) {
+            // partial dh_{t-1}[:, 16 c .. 16 c + 15] for every consumer c; wave w takes c = w, w+4, ...
+            const int slot = s & (KS_SLOTS - 1);
+            if constexpr (PREC == LAS_PREC_BF16) {
+                bf16x8 dv[NB][2];
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        dv[bt][ks] = *(const bf16x8*)((const bf16_t*)Dl + (bt * 16 + fr) * LDK + ks * 32 + fq * 8);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int c = wave + 4 * i;
+                    if (c >= G) break;
+                    unsigned* dst = inbox(slot, c, g);
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) {
+                        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][0], dv[bt][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][1], dv[bt][1], acc, 0, 0, 0);
+                        // lane: batch row bt*16 + fr, output columns 16c + 4 fq + {0..3}
+                        const int row = bt * 16 + fr;
+                        if (row < Bl) {
+                            const unsigned long long v = (unsigned long long)pack_bf16x2(acc[0], acc[1]) |
+                                                         ((unsigned long long)pack_bf16x2(acc[2], acc[3]) << 32);
+                            __hip_atomic_store((unsigned long long*)(dst + row * WPR + fq * 2), v, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            } else {
+                for (int c = wave; c < G; c += 4) {
+                    unsigned* dst = inbox(slot, c, g);
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) {
+                        f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+                        mma_rows<PREC, 1>(acc, Wl + (size_t)c * 16 * LDK, LDK, Dl + bt * 16 * LDK, LDK, KO / KSTEP);
+                        const int row = bt * 16 + fr;
+                        if (row < Bl) {
+                            const u32x4 v = {__float_as_uint(acc[0][0]), __float_as_uint(acc[0][1]), __float_as_uint(acc[0][2]),
+                                             __float_as_uint(acc[0][3])};
+                            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, WPT * 4, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * WPR + fq * 4) * 4, 0, 16);
+                        }
+                    }
+                }
+            }
+            block_signal(cnt);
+        }
+        // fp32 copy for the weight-gradient GEMMs, then next step's inputs
+        if (ev) {
+            const long ro = (long)t * B + b0 + eb;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+                *(float2*)(dgf + ro * ND4H + d * K4 + gi * H + j) = make_float2(dg[gi][0], dg[gi][1]);
+        }
+        load_inputs(s + 1);
+    }
+}
+
+size_t bwd_ks_lds(int prec, int H, int NB) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, G = (H + 15) / 16;
+    return (size_t)(G * 16 + NB * 16) * (64 + vec) * sz + sizeof(unsigned) * (size_t)G * ks_words_per_tile(prec, NB) +
+           sizeof(int) * (NB * 16 + 4);
+}
+size_t bwd_ks_ring_bytes(int prec, int H, int ND, int NS, int NB) {
+    const size_t G = (H + 15) / 16;
+    return sizeof(unsigned) * KS_SLOTS * ND * NS * G * G * ks_words_per_tile(prec, NB);
+}
+
 size_t fwd_lds(int prec, int H, int NB) {
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ks = prec == LAS_PREC_BF16 ? 32 : 16;
     const int Kp = (H + ks - 1) / ks * ks, ld = Kp + vec;
@@ -536,6 +761,15 @@ extern "C" void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int
 
 extern "C" size_t las_lstm_sync_bytes(void) { return sizeof(SyncWords); }
 
+extern "C" size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND) {
+    LstmArgs a;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    const int NB = las_pick_nb(a.Bs);
+    const size_t gather = (size_t)ND * T * B * 4 * H * (prec == LAS_PREC_BF16 ? 2 : 4);     // all-gather variant: dgates copy
+    const size_t ring = NB >= 1 && NB <= 2 ? bwd_ks_ring_bytes(prec, H, ND, a.NS, NB) : 0;   // K-split variant: inbox ring
+    return gather > ring ? gather : ring;
+}
+
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                                 const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
                                 float* hf, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
@@ -594,6 +828,26 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
+    // K-split exchange (reduce-scatter of partial dh) whenever its weight slab fits in LDS
+    if (NB <= 2 && bwd_ks_lds(prec, H, NB) <= LDS_CAP && !getenv("LAS_LSTM_BWD_GATHER")) {
+        size_t l2 = bwd_ks_lds(prec, H, NB);
+        if (l2 < MIN_LDS) l2 = MIN_LDS;
+#define LAS_KS_GO(P_, N_, M_)                                                                                          \
+    {                                                                                                                 \
+        auto k = lstm_bwd_ks_kernel<P_, N_, M_>;                                                                      \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));            \
+        hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), l2, st, a, dy, gates, cs, w_hh, lens, (unsigned*)dgx, dgf, \
+                           (SyncWords*)sync, status);                                                                 \
+        LAS_LAUNCH_OK();                                                                                              \
+        return LAS_OK;                                                                                                \
+    }
+        const int mt = (a.G + 3) / 4;
+        if (prec == LAS_PREC_BF16) {
+            if (NB == 1) { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 1, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 1, 8) else if (mt <= 16) LAS_KS_GO(LAS_PREC_BF16, 1, 16) }
+            else { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 2, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 2, 8) else if (mt <= 16) LAS_KS_GO(LAS_PREC_BF16, 2, 16) }
+        } else { if (NB == 1) LAS_KS_GO(LAS_PREC_F32, 1, 1) else LAS_KS_GO(LAS_PREC_F32, 2, 1) }
+#undef LAS_KS_GO
+    }
 #define LAS_BWD_ARGS a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
         const int kq = K4p / 32 / 4;                        // k-steps per wave

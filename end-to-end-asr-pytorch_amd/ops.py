@@ -365,8 +365,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     ND, H4, H = w_hh.shape
     dev = x.device
     gy = gy.contiguous()
-    esz = 2 if prec == 0 else 4
-    dgx = torch.empty(ND * T * B * H4 * esz, dtype=torch.uint8, device=dev)
+    dgx = torch.empty(L_.las_lstm_bwd_ws_bytes(I(prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
     with _Timed('lstm_rec_bwd (persistent BiLSTM BPTT)', 2.0 * ND * T * B * H4 * H, 'flop'):

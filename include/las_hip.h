@@ -67,11 +67,12 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  *   gates [T][B][ND*4H] post-activation gates, cs [T][B][ND*H] cell states (saved for bwd)
  *   sync  las_lstm_sync_bytes() bytes of scratch; status: int32, caller-zeroed, set to LAS_E_TIMEOUT if
  *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).
- * bwd: dy [T_out][B][F_out] -> dgf [T][B][ND*4H] (= d loss / d xproj, fp32) and dgx [ND][T][B][4H]
- * (exchange copy, operand type).  dW_ih, dW_hh, db, dx follow from dgf through las_gemm / las_colsum.
+ * bwd: dy [T_out][B][F_out] -> dgf [T][B][ND*4H] (= d loss / d xproj, fp32); dgx is the exchange workspace of
+ * las_lstm_bwd_ws_bytes() bytes (a ring of partial-dh inboxes, or the dgates copy of the all-gather variant).  dW_ih, dW_hh, db, dx follow from dgf through las_gemm / las_colsum.
  * Limits: H % 2 == 0, B <= 2048 (the batch is cut into independent slices of <= 128 rows, normally ~12), ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
 void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
 size_t las_lstm_sync_bytes(void);
+size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size of the `dgx` exchange workspace of rec_bwd */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
                      void* hx, float* gates, float* cs, void* sync, int* status, void* stream);

@@ -17,6 +17,12 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
                       long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
                       float* gates_out, hipStream_t st);
 
+int las_skinny_launch_pw(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                         long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                         long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                         long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                         float* gates_out, const las_skinny_pw* pw, hipStream_t st);
+
 namespace {
 
 constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;
@@ -474,16 +480,21 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
     if (loc) lds_e += sizeof(float) * (A + LOC_C * (size_t)A + LOC_C * TC + ATT_NW * (size_t)A + LOC_C * LOC_W + LOC_C * (TC + 2 * LOC_K));
     const size_t lds_cw = sizeof(float) * ((size_t)Tp + 2 * LOC_K + CW_KPT + LOC_C * (size_t)Tp);
     if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
+    const bool fuse_pw = NL == 1;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
             const float* dh_ext = (l == NL - 1) ? g_htop + (long)t * BC : w.d_below;
             float* dg = w.dgates + ((long)l * L + t) * B * 4 * C;
-            hipLaunchKernelGGL(cell_pw_bwd, dim3((B * C + 255) / 256), dim3(256), 0, st, B, C, dh_ext, (long)C,
-                               w.dh_carry + (long)l * BC, w.dc_carry + (long)l * BC,
-                               s.gates + ((long)l * L + t) * B * 4 * C, s.cs + ((long)l * (L + 1) + t + 1) * BC,
-                               s.cs + ((long)l * (L + 1) + t) * BC, dg);
-            LAS_LAUNCH_OK();
+            // single-layer decoders: the cell backward of step t < L-1 already ran in the epilogue of step t+1's
+            // recurrent product (below), which is where its dh comes from
+            if (!(fuse_pw && t < L - 1)) {
+                hipLaunchKernelGGL(cell_pw_bwd, dim3((B * C + 255) / 256), dim3(256), 0, st, B, C, dh_ext, (long)C,
+                                   w.dh_carry + (long)l * BC, w.dc_carry + (long)l * BC,
+                                   s.gates + ((long)l * L + t) * B * 4 * C, s.cs + ((long)l * (L + 1) + t + 1) * BC,
+                                   s.cs + ((long)l * (L + 1) + t) * BC, dg);
+                LAS_LAUNCH_OK();
+            }
             const int Kx = l == 0 ? (int)XI : C;
             float* dx = l == 0 ? w.dxin + (long)t * B * XI : w.d_below;
             int rc = las_skinny_launch(prec, dg, 4 * C, p->w_ihT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr,
@@ -535,9 +546,15 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
         // ---- dh0_{t-1} = dgates_{0,t} * W_hh + dq_pre_t * W_phi   (one two-segment product)
         if (t > 0) {
             const float* dg0 = w.dgates + (long)t * B * 4 * C;
-            int rc = las_skinny_launch(prec, dg0, 4 * C, p->w_hhT[0], 4 * C, 4 * C, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A,
-                                       nullptr, 0, nullptr, 0, 0, B, C, nullptr, nullptr, 0, w.dh_carry, C, 0, 0, nullptr, nullptr,
-                                       nullptr, nullptr, st);
+            las_skinny_pw pw{};
+            if (fuse_pw) {                                // cell backward of step t-1 rides on this product
+                pw.dh_ext = g_htop + (long)(t - 1) * BC; pw.ld_ext = C; pw.dc_carry = w.dc_carry;
+                pw.gates = s.gates + (long)(t - 1) * B * 4 * C; pw.c_t = s.cs + (long)t * BC; pw.c_prev = s.cs + (long)(t - 1) * BC;
+                pw.dgates = w.dgates + (long)(t - 1) * B * 4 * C;
+            }
+            int rc = las_skinny_launch_pw(prec, dg0, 4 * C, p->w_hhT[0], 4 * C, 4 * C, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A,
+                                          nullptr, 0, nullptr, 0, 0, B, C, nullptr, nullptr, 0, w.dh_carry, C, 0, 0, nullptr, nullptr,
+                                          nullptr, nullptr, fuse_pw ? &pw : nullptr, st);
             if (rc) return rc;
         }
     }

@@ -50,6 +50,15 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f / (e + 1.f);
 }
 
+// Cell pointwise backward of the EARLIER decode step, fused into the skinny product that yields its recurrent dh
+// (skinny.hip mode 3): pointers are that step's slabs.
+struct las_skinny_pw {
+    const float* dh_ext; long ld_ext;     // upstream gradient d loss / d h_top of that step, [B][ld_ext]
+    float* dc_carry;                      // [B][C] running d c (updated in place)
+    const float* gates; const float* c_t; const float* c_prev;   // saved [B][4C], [B][C], [B][C]
+    float* dgates;                        // [B][4C] out
+};
+
 inline int las_pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
 
 #define LAS_NB_SWITCH(NBV, CALL)                        \

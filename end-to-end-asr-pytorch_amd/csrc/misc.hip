@@ -31,22 +31,22 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
         for (long k = i; k < n; ++k) out[k] = dy[k] * (1.f - y[k] * y[k]);
 }
 
-// lens[b] = #frames whose feature sum != 0   (reference solver.py:134, done on the host there)
+// lens[b] = #frames whose feature sum != 0   (reference solver.py:134, done on the host there).
+// grid (B, T-chunks of 64 frames): a wave sums 16 frames, integer atomics add the chunk counts (lens zeroed first).
+constexpr int IL_FRAMES = 64;
 __global__ __launch_bounds__(256) void infer_lengths_kernel(const float* __restrict__ x, int T, int D,
                                                             int32_t* __restrict__ lens) {
-    __shared__ float red[32];
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float cnt = 0.f;
-    for (int t = w; t < T; t += 4) {
+    const int t0 = blockIdx.y * IL_FRAMES, t1 = min(t0 + IL_FRAMES, T);
+    int cnt = 0;
+    for (int t = t0 + w; t < t1; t += 4) {
         const float* r = x + ((long)b * T + t) * D;
         float s = 0.f;
         for (int i = lane; i < D; i += 64) s += r[i];
         s = wave_sum(s);
-        if (s != 0.f) cnt += 1.f;
+        if (s != 0.f) ++cnt;
     }
-    if (lane != 0) cnt = 0.f;
-    cnt = block_sum(cnt, red);
-    if (threadIdx.x == 0) lens[b] = (int)cnt;
+    if (lane == 0 && cnt) atomicAdd(&lens[b], cnt);
 }
 
 // out[b] = #nonzero labels in y[b,:] (int64)   (reference solver.py:136,159)
@@ -94,7 +94,8 @@ extern "C" int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t
 
 extern "C" int las_infer_lengths(const float* x, int B, int T, int D, int32_t* lens, void* stream) {
     LAS_CHECK_ARG(x && lens && B > 0 && T > 0 && D > 0);
-    hipLaunchKernelGGL(infer_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, T, D, lens);
+    LAS_HIP(hipMemsetAsync(lens, 0, sizeof(int32_t) * B, (hipStream_t)stream));
+    hipLaunchKernelGGL(infer_lengths_kernel, dim3(B, (T + IL_FRAMES - 1) / IL_FRAMES), dim3(256), 0, (hipStream_t)stream, x, T, D, lens);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

@@ -25,11 +25,15 @@ struct SkinnyArgs {
     Seg seg[3];
     int ns, B, N;
     const float* bias0; const float* bias1;
-    int mode;                 // 0 store, 1 tanh, 2 lstm cell
+    int mode;                 // 0 store, 1 tanh, 2 lstm cell, 3 product = dh of the PREVIOUS decode step -> its cell backward
     float* out; long ldo; int accumulate;
     // cell mode: N = 4*C gate rows (i,f,g,o blocks of C); tile column c -> gate c>>2, unit blk*4 + (c&3)
     int C;
     const float* c_prev; float* h_out; float* c_out; float* gates_out;
+    // mode 3 (N = C): out[b][n] is d loss / d h of the earlier step through the recurrence; with the upstream gradient
+    // dh_ext it goes straight through that step's cell pointwise backward (decoder_bwd.hip cell_pw_bwd) for element (b,n)
+    const float* pw_dh_ext; long pw_ld_ext; float* pw_dc_carry; const float* pw_gates; const float* pw_c_t;
+    const float* pw_c_prev; float* pw_dgates;
 };
 
 // Stage `nrows` rows x n columns (fp32 source, row r at base + rowidx(r)*ldsrc) into tile[r][dcol..dcol+n) with all
@@ -73,13 +77,22 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
 // Epilogue operands of a thread's FIRST output element (bias, old output when accumulating, previous cell state):
 // requested at kernel entry so that their memory round trip overlaps the weight stream instead of following the
 // reduction barrier.
-struct SkinnyPre { float bias[4]; float old; };
+struct SkinnyPre { float bias[4]; float old; float pw[4]; };
 template <int NWAVES>
 __device__ __forceinline__ SkinnyPre skinny_prefetch(const SkinnyArgs& a, int blk) {
     SkinnyPre p;
     p.bias[0] = p.bias[1] = p.bias[2] = p.bias[3] = 0.f; p.old = 0.f;
     const int e = threadIdx.x;
-    if (a.mode != 2) {
+    p.pw[0] = p.pw[1] = p.pw[2] = p.pw[3] = 0.f;
+    if (a.mode == 3) {
+        const int b = min(e >> 4, a.B - 1), n = min(blk * 16 + (e & 15), a.N - 1);
+        const long i = (long)b * a.N + n;
+        const float* g = a.pw_gates + (long)b * 4 * a.N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p.bias[q] = g[q * a.N + n];                 // i, f, g, o of the earlier step
+        p.old = a.pw_dh_ext[(long)b * a.pw_ld_ext + n];
+        p.pw[0] = a.pw_c_t[i]; p.pw[1] = a.pw_c_prev[i]; p.pw[2] = a.pw_dc_carry[i];
+    } else if (a.mode != 2) {
         const int b = min(e >> 4, a.B - 1), n = min(blk * 16 + (e & 15), a.N - 1);
         if (a.bias0) p.bias[0] = a.bias0[n];
         if (a.bias1) p.bias[0] += a.bias1[n];
@@ -109,7 +122,28 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
         const int n = blk * 16 + c;
         return n < a.N ? n : -1;
     };
-    if (a.mode != 2) {
+    if (a.mode == 3) {
+        for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
+            const int b = e >> 4, c = e & 15, n = wrow(c);
+            if (n < 0) continue;
+            const bool first = e == (int)threadIdx.x;
+            const long i = (long)b * a.N + n;
+            const float* g = a.pw_gates + (long)b * 4 * a.N;
+            const float ig = first ? pre0.bias[0] : g[n], fg = first ? pre0.bias[1] : g[a.N + n];
+            const float gg = first ? pre0.bias[2] : g[2 * a.N + n], og = first ? pre0.bias[3] : g[3 * a.N + n];
+            const float dh = (first ? pre0.old : a.pw_dh_ext[(long)b * a.pw_ld_ext + n]) + gsum(b, c);
+            const float ct = first ? pre0.pw[0] : a.pw_c_t[i], cp = first ? pre0.pw[1] : a.pw_c_prev[i];
+            const float dcc = first ? pre0.pw[2] : a.pw_dc_carry[i];
+            const float tc = tanhf(ct);
+            const float dc = dh * og * (1.f - tc * tc) + dcc;
+            float* d = a.pw_dgates + (long)b * 4 * a.N;
+            d[n] = dc * gg * ig * (1.f - ig);
+            d[a.N + n] = dc * cp * fg * (1.f - fg);
+            d[2 * a.N + n] = dc * ig * (1.f - gg * gg);
+            d[3 * a.N + n] = dh * tc * og * (1.f - og);
+            a.pw_dc_carry[i] = dc * fg;
+        }
+    } else if (a.mode != 2) {
         for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
             const int b = e >> 4, c = e & 15, row = wrow(c);
             if (row < 0) continue;
@@ -320,11 +354,11 @@ int launch(const SkinnyArgs& a, size_t lds, int KC, int NCK, int grid, hipStream
 }  // namespace
 
 // Internal C++ entry used by the decoder driver (decoder.hip) and by the public wrappers below.
-int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
-                      long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
-                      long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
-                      long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
-                      float* gates_out, hipStream_t st) {
+int las_skinny_launch_pw(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                         long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                         long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                         long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                         float* gates_out, const las_skinny_pw* pw, hipStream_t st) {
     SkinnyArgs a{};
     a.seg[0] = Seg{x0, ldx0, w0, ldw0, K0};
     a.seg[1] = Seg{x1, ldx1, w1, ldw1, K1};
@@ -332,6 +366,12 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
     a.ns = x2 ? 3 : (x1 ? 2 : 1);
     a.B = B; a.N = N; a.bias0 = bias0; a.bias1 = bias1; a.mode = mode; a.out = out; a.ldo = ldo;
     a.accumulate = accumulate; a.C = C; a.c_prev = c_prev; a.h_out = h_out; a.c_out = c_out; a.gates_out = gates_out;
+    if (pw) {
+        if (mode != 0 || accumulate || bias0 || bias1) return LAS_E_BADARG;
+        a.mode = 3;
+        a.pw_dh_ext = pw->dh_ext; a.pw_ld_ext = pw->ld_ext; a.pw_dc_carry = pw->dc_carry; a.pw_gates = pw->gates;
+        a.pw_c_t = pw->c_t; a.pw_c_prev = pw->c_prev; a.pw_dgates = pw->dgates;
+    }
     const int NB = las_pick_nb(B);
     if (NB == 0 || B <= 0 || N <= 0 || K0 <= 0) return LAS_E_UNSUPPORTED;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
@@ -354,6 +394,15 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
     if (prec == LAS_PREC_BF16) { LAS_NB_SWITCH(NB, return (launch<LAS_PREC_BF16, NB_>(a, lds, KC, NCK, grid, st))); }
     else { LAS_NB_SWITCH(NB, return (launch<LAS_PREC_F32, NB_>(a, lds, KC, NCK, grid, st))); }
     return LAS_E_BADARG;
+}
+
+int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                      long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                      long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                      long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                      float* gates_out, hipStream_t st) {
+    return las_skinny_launch_pw(prec, x0, ldx0, w0, ldw0, K0, x1, ldx1, w1, ldw1, K1, x2, ldx2, w2, ldw2, K2, B, N, bias0, bias1,
+                                mode, out, ldo, accumulate, C, c_prev, h_out, c_out, gates_out, nullptr, st);
 }
 
 extern "C" int las_lstm_cell_fwd(int prec, const float* x, int64_t ldx, int Kx, const float* h_prev, const float* c_prev,

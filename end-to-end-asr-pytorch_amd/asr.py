@@ -5,7 +5,7 @@ Attention and Speller, so checkpoints and the Trainer code carry over; every ten
 All parameters (and their gradients) are views of one flat fp32 buffer each, which the fused optimiser and the
 RCCL gradient all-reduce treat as a single vector.
 
-Not built here (out of scope): multi-head attention (broken in the reference, asr.py:436), GRU cells, dropout > 0.
+Not built here (out of scope): multi-head attention (broken in the reference, asr.py:436), GRU cells.
 """
 import math
 import random
@@ -80,8 +80,8 @@ class Seq2Seq(nn.Module):
         self.srs = [int(v) for v in str(enc['sample_rate']).split('_')]
         drops = [float(v) for v in str(enc['dropout']).split('_')]
         assert len(self.srs) == len(drops) == len(self.dims), 'Number of layer mismatch'      # asr.py:279-280
-        if any(d > 0 for d in drops):
-            raise NotImplementedError('encoder dropout > 0 is not built')
+        # encoder `dropout` is accepted and has no effect, exactly as in the reference: it is handed to
+        # nn.LSTM(num_layers=1, dropout=p) (asr.py:473), which applies dropout only BETWEEN stacked layers
         self.bidir = 'Bi' in enc['enc_type']
         if 'RNN' not in enc['enc_type']:
             raise ValueError('Unsupported Encoder Type: ' + enc['enc_type'])
@@ -121,8 +121,8 @@ class Seq2Seq(nn.Module):
                 raise NotImplementedError('attention without projection is not built')
             if dec['rnn_cell'] != 'LSTMCell':
                 raise NotImplementedError('only LSTMCell decoders are built')
-            if float(dec['dropout']) > 0:
-                raise NotImplementedError('decoder dropout > 0 is not built')
+            self.dec_dropout = float(dec['dropout'])                  # Speller dropout, asr.py:327,353,355
+            self.drop_calls = 0
             self.att_mode = att['att_mode'].lower()
             if self.att_mode not in ('dot', 'loc'):
                 raise ValueError('Unsupported Attention Mode: ' + self.att_mode)
@@ -271,6 +271,9 @@ class Seq2Seq(nn.Module):
             ws = [self.P(n) for n in weight_names(self.dec_layers, loc)]
             self.sample_seed += 1
             seed = (torch.initial_seed() + 1000003 * self.sample_seed) & 0x7fffffff
+            if self.training and self.dec_dropout > 0:
+                self.drop_calls += 1
+                seed = (seed, self.dec_dropout, (torch.initial_seed() * 2654435761 + self.drop_calls) & 0xffffffff)
             h_top, att = DecoderFn.apply(enc, psi, enc_len_dev, y, L, self.dec_layers, loc, step_mode, seed, *ws)
             logits = ops.linear(h_top, self.P('char_trans.weight'), self.P('char_trans.bias'))     # [L,B,V]
             att_output = ops.Transpose01Fn.apply(logits)

@@ -340,11 +340,24 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
             hipLaunchKernelGGL(embed_rows_kernel, dim3(B), dim3(256), 0, st, p->emb, nullptr, 0, s.tok, B, C, V, xin_t, XI, nullptr);
             LAS_LAUNCH_OK();
         }
-        // LSTM cells (reference asr.py:352-357; dropout 0)
+        // LSTM cells (reference asr.py:352-357): dropout on the cell-0 input, and on the recurrent state of layers >= 1
+        const bool drop = d->dropout > 0.f;
+        if (drop) {
+            LAS_CHECK_ARG(s.xdrop && (NL == 1 || s.hdrop));
+            rc = las_dropout_rows(xin_t, XI, s.xdrop + (long)t * B * XI, XI, B, (int)XI, d->dropout,
+                                  las_decoder_drop_seed(d->drop_seed, t, 0), stream);
+            if (rc) return rc;
+        }
         for (int l = 0; l < NL; ++l) {
-            const float* x = l == 0 ? xin_t : s.hs + ((long)(l - 1) * (L + 1) + t + 1) * BC;
+            const float* x = l == 0 ? (drop ? s.xdrop + (long)t * B * XI : xin_t) : s.hs + ((long)(l - 1) * (L + 1) + t + 1) * BC;
             const int Kx = l == 0 ? (int)XI : C;
             const float* hp = s.hs + ((long)l * (L + 1) + t) * BC;
+            if (drop && l > 0) {
+                float* hd = s.hdrop + ((long)l * L + t) * BC;
+                rc = las_dropout_rows(hp, C, hd, C, B, C, d->dropout, las_decoder_drop_seed(d->drop_seed, t, l), stream);
+                if (rc) return rc;
+                hp = hd;
+            }
             const float* cp = s.cs + ((long)l * (L + 1) + t) * BC;
             rc = las_skinny_launch(prec, x, Kx, p->w_ih[l], Kx, Kx, hp, C, p->w_hh[l], C, C, nullptr, 0, nullptr, 0, 0, B, 4 * C,
                                    p->b_ih[l], p->b_hh[l], 2, nullptr, 0, 0, C, cp, s.hs + ((long)l * (L + 1) + t + 1) * BC,

@@ -481,6 +481,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
     const size_t lds_cw = sizeof(float) * ((size_t)Tp + 2 * LOC_K + CW_KPT + LOC_C * (size_t)Tp);
     if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
     const bool fuse_pw = NL == 1;
+    const bool drop = d->dropout > 0.f;
     for (int t = L - 1; t >= 0; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
@@ -500,6 +501,10 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             int rc = las_skinny_launch(prec, dg, 4 * C, p->w_ihT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr,
                                        0, 0, B, Kx, nullptr, nullptr, 0, dx, Kx, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
             if (rc) return rc;
+            if (drop && l == 0) {                      // d xin = d(xdrop) * mask of the forward pass
+                rc = las_dropout_rows(dx, Kx, dx, Kx, B, Kx, d->dropout, las_decoder_drop_seed(d->drop_seed, t, 0), stream);
+                if (rc) return rc;
+            }
             // recurrent carry dh_{l,t-1} = dgates * W_hh; layer 0 gets the attention-query path in the same product
             // (second k-segment dq_pre_t * W_phi) and is therefore launched after the attention backward below
             if (l > 0 && t > 0) {
@@ -507,6 +512,11 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
                                        0, B, C, nullptr, nullptr, 0, w.dh_carry + (long)l * BC, C, 0, 0, nullptr, nullptr, nullptr,
                                        nullptr, st);
                 if (rc) return rc;
+                if (drop) {                            // layer l >= 1 saw dropout(h_{l,t-1}) as its recurrent state
+                    rc = las_dropout_rows(w.dh_carry + (long)l * BC, C, w.dh_carry + (long)l * BC, C, B, C, d->dropout,
+                                          las_decoder_drop_seed(d->drop_seed, t, l), stream);
+                    if (rc) return rc;
+                }
             }
         }
         // ---- attention of step t

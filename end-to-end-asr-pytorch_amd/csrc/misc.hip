@@ -72,6 +72,20 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
         if (c0 + i < C && r0 + tx < R) out[(long)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+__device__ __forceinline__ unsigned drop_hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                           long ldo, int R, int N, float p, float scale, unsigned seed) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)R * N) return;
+    const int r = (int)(idx / N), i = (int)(idx - (long)r * N);
+    const unsigned h = drop_hash32(seed ^ drop_hash32((unsigned)idx * 0x9e3779b9u + 0x85ebca6bu));
+    const float u = (float)(h >> 8) * (1.f / 16777216.f);
+    out[(long)r * ldo + i] = u >= p ? in[(long)r * ldi + i] * scale : 0.f;
+}
+
 }  // namespace
 
 extern "C" int las_transpose01(const float* in, float* out, int D0, int D1, int F, void* stream) {
@@ -112,4 +126,18 @@ extern "C" int las_transpose2d(const float* in, float* out, int R, int C, void* 
     hipLaunchKernelGGL(transpose2d_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
     LAS_LAUNCH_OK();
     return LAS_OK;
+}
+
+extern "C" int las_dropout_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, int N, float p, unsigned seed,
+                                void* stream) {
+    LAS_CHECK_ARG(in && out && R >= 0 && N > 0 && ld_in >= N && ld_out >= N && p >= 0.f && p < 1.f);
+    if (R == 0) return LAS_OK;
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)(((long)R * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (long)ld_in, out, (long)ld_out, R, N, p, 1.f / (1.f - p), seed);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+extern "C" unsigned las_decoder_drop_seed(unsigned drop_seed, int step, int layer) {
+    return drop_seed * 0x9E3779B1u + (unsigned)step * 131u + (unsigned)layer * 7919u + 1u;
 }

@@ -10,7 +10,8 @@ LOC_C, LOC_W = 10, 201
 
 
 class DecDims(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int) for n in ('B', 'Tp', 'E', 'A', 'C', 'NL', 'V', 'L', 'loc', 'prec')]
+    _fields_ = ([(n, ctypes.c_int) for n in ('B', 'Tp', 'E', 'A', 'C', 'NL', 'V', 'L', 'loc', 'prec')] +
+                [('dropout', ctypes.c_float), ('drop_seed', ctypes.c_uint)])
 
 
 class DecParams(ctypes.Structure):
@@ -21,7 +22,7 @@ class DecParams(ctypes.Structure):
 
 class DecState(ctypes.Structure):
     _fields_ = [('tok', P), ('xin', P), ('q', P), ('att', P), ('hs', P), ('cs', P), ('gates', P), ('f', P), ('s', P),
-                ('ebuf', P), ('logits_step', P)]
+                ('ebuf', P), ('logits_step', P), ('xdrop', P), ('hdrop', P)]
 
 
 def _p(t):
@@ -63,19 +64,23 @@ def alloc_state(dims, dev):
     if d.loc:
         S['f'] = torch.empty(d.L, d.B, LOC_C, d.Tp, **f32)
         S['s'] = torch.empty(d.L, d.B, d.Tp, d.A, **f32)
+    if d.dropout > 0:
+        S['xdrop'] = torch.empty(d.L, d.B, d.C + d.E, **f32)
+        if d.NL > 1:
+            S['hdrop'] = torch.empty(d.NL, d.L, d.B, d.C, **f32)
     st = DecState()
     for k, v in S.items():
         setattr(st, k, v.data_ptr())
     return S, st
 
 
-def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, seed=0):
+def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, seed=0, dropout=0.0, drop_seed=0):
     """Runs las_decoder_fwd; returns the dict of saved-state tensors (used by tests and by DecoderFn)."""
     L_ = _lib.lib()
     B, Tp, E = enc.shape
     A = psi.shape[-1]
     V, C = W['embed.weight'].shape
-    dims = DecDims(B, Tp, E, A, C, NL, V, L, int(loc), ops._prec)
+    dims = DecDims(B, Tp, E, A, C, NL, V, L, int(loc), ops._prec, float(dropout), int(drop_seed) & 0xffffffff)
     params = make_params(W, NL, loc)
     S, st = alloc_state(dims, enc.device)
     sm = None
@@ -119,7 +124,8 @@ def weight_names(NL, loc):
 
 class DecoderFn(torch.autograd.Function):
     """All L attend-and-spell steps (reference asr.py:77-107) and their BPTT.
-    forward(enc [B,T',E], psi [B,T',A], enc_len i32 [B], y i64 [B,Ly] | None, L, NL, loc, step_mode, seed, *weights)
+    forward(enc [B,T',E], psi [B,T',A], enc_len i32 [B], y i64 [B,Ly] | None, L, NL, loc, step_mode, seed | (seed,
+    dropout, drop_seed), *weights)
       -> h_top [L,B,C] (time-major top-layer states), att [L,B,T'] (non-differentiable)."""
 
     @staticmethod
@@ -127,7 +133,10 @@ class DecoderFn(torch.autograd.Function):
         names = weight_names(NL, loc)
         W = dict(zip(names, weights))
         enc, psi = enc.contiguous(), psi.contiguous()
-        S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed)
+        dropout, drop_seed = 0.0, 0
+        if isinstance(seed, tuple):
+            seed, dropout, drop_seed = seed
+        S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, dropout, drop_seed)
         ctx.S, ctx.W, ctx.cfg = S, W, (L, NL, loc, names)
         ctx.save_for_backward(enc, psi, enc_len)
         h_top = S['hs'][NL - 1, 1:]
@@ -181,9 +190,11 @@ class DecoderFn(torch.autograd.Function):
             ops.gemm(Bw['dq_pre'].view(LB, A), hs0_prev, out['attention.phi.weight'], transA=True, beta=beta)
             for l in range(NL):
                 dg = Bw['dgates'][l].view(LB, 4 * C)
-                x_l = S['xin'].view(LB, XI) if l == 0 else S['hs'][l - 1, 1:].reshape(LB, C)
+                # with dropout the cells saw the dropped copies (asr.py:353,355)
+                x_l = (S['xdrop'] if 'xdrop' in S else S['xin']).view(LB, XI) if l == 0 else S['hs'][l - 1, 1:].reshape(LB, C)
+                h_l = S['hdrop'][l] if (l > 0 and 'hdrop' in S) else S['hs'][l, :L]
                 ops.gemm(dg, x_l, out[f'decoder.layer{l}.weight_ih'], transA=True, beta=beta)
-                ops.gemm(dg, S['hs'][l, :L].reshape(LB, C), out[f'decoder.layer{l}.weight_hh'], transA=True, beta=beta)
+                ops.gemm(dg, h_l.reshape(LB, C), out[f'decoder.layer{l}.weight_hh'], transA=True, beta=beta)
                 ops.colsum(dg, out[f'decoder.layer{l}.bias_ih'], beta=beta)
                 ops.colsum(dg, out[f'decoder.layer{l}.bias_hh'], beta=beta)
 

@@ -109,6 +109,10 @@ typedef struct {
     int B, Tp, E, A, C, NL, V, L;   /* batch, encoder frames, enc dim, att dim, dec dim, dec layers, vocab, steps */
     int loc;                        /* 0: dot attention, 1: location-aware */
     int prec;
+    float dropout;                  /* Speller dropout (asr.py:327,353,355): on the cell-0 input and on the recurrent
+                                       state of layers >= 1; 0 disables (eval mode).  Masks are a counter hash of
+                                       (drop_seed, step, layer, element): las_dropout_rows with las_decoder_drop_seed() */
+    unsigned drop_seed;
 } las_dec_dims;
 typedef struct {
     const float* emb;               /* embed.weight [V][C] */
@@ -140,6 +144,8 @@ typedef struct {                    /* saved activations, written by fwd, read b
     float* s;                       /* loc: [L][B][Tp][A] tanh(psi + q + u) */
     float* ebuf;                    /* [B][Tp] scratch */
     float* logits_step;             /* [B][V] scratch (sampled / greedy steps) */
+    float* xdrop;                   /* dropout > 0: [L][B][C+E] cell-0 input after dropout (xin keeps the clean one) */
+    float* hdrop;                   /* dropout > 0, NL > 1: [NL][L][B][C] recurrent state of layers >= 1 after dropout */
 } las_dec_state;
 /* step_mode[t] (host): how the token fed at step t is chosen: 1 teacher y[:,t], 0 sampled from softmax of
  * step t-1's logits, 2 argmax of step t-1's logits.  step_mode==NULL means all teacher.  y [B][Ly] int64. */
@@ -203,6 +209,13 @@ int las_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, f
                   const float* norm3, const int32_t* step_dev, int zero_grad, void* stream);
 int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps,
                       const float* norm3, int zero_grad, void* stream);
+
+/* inverted dropout on rows: out[r][i] = keep ? in[r][i] / (1-p) : 0, keep = hash(seed, r*N+i) >= p (nn.Dropout at
+ * asr.py:327; same distribution, not torch's stream).  in == out allowed.  las_decoder_drop_seed: the seed the decoder
+ * uses for (step, layer). */
+int las_dropout_rows(const float* in, int64_t ld_in, float* out, int64_t ld_out, int R, int N, float p, unsigned seed,
+                     void* stream);
+unsigned las_decoder_drop_seed(unsigned drop_seed, int step, int layer);
 
 /* training-time accuracy on the device: pred = argmax rows of att_pred; token accuracy up to the first 0 label,
  * mean over utterances (np.argmax + cal_acc at src/postprocess.py:121-133, called every step at solver.py:187) */

@@ -224,13 +224,18 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return torch.sigmoid(o) * torch.tanh(c), c
 
 
-def speller_step(inp, hs, cs, W, n_layers):
-    """asr.py:352-357 with dropout 0."""
+def speller_step(inp, hs, cs, W, n_layers, masks=None):
+    """asr.py:352-357.  masks (dropout replay): masks[0] multiplies the cell-0 input (asr.py:353), masks[l] the
+    recurrent state h_l of layer l >= 1 (asr.py:355: dropout sits on the hidden input, not on the layer input); each
+    already scaled by 1/(1-p).  None = dropout 0 / eval."""
     p = 'decoder.layer'
+    if masks is not None:
+        inp = inp * masks[0]
     hs[0], cs[0] = lstm_cell(inp, hs[0], cs[0], W[p + '0.weight_ih'], W[p + '0.weight_hh'],
                              W[p + '0.bias_ih'], W[p + '0.bias_hh'])
     for l in range(1, n_layers):
-        hs[l], cs[l] = lstm_cell(hs[l - 1], hs[l], cs[l], W[f'{p}{l}.weight_ih'], W[f'{p}{l}.weight_hh'],
+        hl = hs[l] * masks[l] if masks is not None else hs[l]
+        hs[l], cs[l] = lstm_cell(hs[l - 1], hl, cs[l], W[f'{p}{l}.weight_ih'], W[f'{p}{l}.weight_hh'],
                                  W[f'{p}{l}.bias_ih'], W[f'{p}{l}.bias_hh'])
     return hs[-1]
 

@@ -1,5 +1,6 @@
 """GPU parity: attend-and-spell decoder loop (HIP, through the C ABI) vs the CPU oracle's step functions.
 f32 mode: atol 3e-5 (attention uses a one-v_exp tanh, abs err ~1e-7 per call); bf16 mode: atol 3e-2."""
+import ctypes
 import importlib
 import numpy as np
 import pytest
@@ -138,3 +139,77 @@ def test_decoder_backward(mods, mode, B, Tp, E, A, C, NL, V, L):
         if k.startswith('char_trans'):
             continue                                      # not used inside the loop
         near(Wg[k].grad, Wt[k].grad, k)
+
+
+@pytest.mark.parametrize('NL', [1, 2])
+def test_decoder_dropout(mods, NL):
+    """Speller dropout (asr.py:327,353,355): the masks the kernels draw (counter hash, exported through
+    las_dropout_rows / las_decoder_drop_seed) are replayed in the oracle; forward states and every gradient must then
+    agree as in the dropout-free test.  Also: keep rate and scaling of the mask itself."""
+    from oracle import las_ref as R
+    ops, dec = mods
+    lib = importlib.import_module('end-to-end-asr-pytorch_amd._lib')
+    L_ = lib.lib()
+    L_.las_decoder_drop_seed.restype = ctypes.c_uint
+    mode, B, Tp, E, A, C, V, L, p, dseed = 'loc', 5, 40, 24, 20, 16, 13, 5, 0.3, 1234567
+    rng = np.random.RandomState(77 + NL)
+    W = rand_weights(rng, V, C, E, A, NL, True)
+    lens = sorted(rng.randint(Tp // 2, Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+
+    def mask(t, l, n):
+        ones = torch.ones(B, n, device=DEV)
+        out = torch.empty_like(ones)
+        seed = L_.las_decoder_drop_seed(ctypes.c_uint(dseed), lib.I(t), lib.I(l))
+        lib.check(L_.las_dropout_rows(lib.P(ones.data_ptr()), ctypes.c_int64(n), lib.P(out.data_ptr()), ctypes.c_int64(n), lib.I(B), lib.I(n),
+                                      ctypes.c_float(p), ctypes.c_uint(seed), lib.cur_stream()), 'dropout')
+        return out.cpu()
+    m0 = mask(0, 0, 4096 // B * B // B)          # statistics on a larger draw
+    big = torch.ones(64, 4096, device=DEV); bo = torch.empty_like(big)
+    lib.check(L_.las_dropout_rows(lib.P(big.data_ptr()), ctypes.c_int64(4096), lib.P(bo.data_ptr()), ctypes.c_int64(4096), lib.I(64), lib.I(4096),
+                                  ctypes.c_float(p), ctypes.c_uint(99), lib.cur_stream()), 'dropout')
+    keep = (bo > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 5e-3 and torch.allclose(bo[bo > 0], torch.tensor(1 / (1 - p), device=DEV))
+    # ---- oracle with the replayed masks
+    Wt = {k: torch.tensor(v, requires_grad=True) for k, v in W.items()}
+    enc_t, psi_t = torch.tensor(enc, requires_grad=True), torch.tensor(psi, requires_grad=True)
+    hs = [torch.zeros(B, C) for _ in range(NL)]
+    cs = [torch.zeros(B, C) for _ in range(NL)]
+    st = R.attention_init(enc_t, lens, Wt)
+    st['psi'] = psi_t
+    tops = []
+    for t in range(L):
+        a, ctx = R.attention_step(hs[0], enc_t, st, Wt, mode)
+        masks = [mask(t, 0, C + E)] + [mask(t, l, C) for l in range(1, NL)]
+        tops.append(R.speller_step(torch.cat([Wt['embed.weight'][torch.tensor(y[:, t])], ctx], -1), hs, cs, Wt, NL, masks))
+    (torch.stack(tops) * torch.tensor(G)).sum().backward()
+    # ---- HIP
+    names = dec.weight_names(NL, True)
+    Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+    enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+    psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+    ops.set_precision('f32')
+    try:
+        h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor(y, device=DEV),
+                                         L, NL, True, None, (0, p, dseed), *[Wg[k] for k in names])
+        (h_top * torch.tensor(G, device=DEV)).sum().backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+
+    def near(got, ref, what):
+        ref = ref.detach().numpy(); got = got.detach().cpu().numpy()
+        err, lim = np.abs(got - ref).max(), 2e-5 + 2e-4 * np.abs(ref).max()
+        assert err <= lim, (what, float(err), float(lim))
+    near(h_top, torch.stack(tops), 'h_top')
+    near(enc_g.grad, enc_t.grad, 'd enc')
+    near(psi_g.grad, psi_t.grad, 'd psi')
+    for k in names:
+        if not k.startswith('char_trans'):
+            near(Wg[k].grad, Wt[k].grad, k)

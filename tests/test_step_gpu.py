@@ -74,3 +74,31 @@ def test_step_vs_reference(las, name, prec):
     assert not bad, bad
     gn = float(torch.sqrt((model.flat_grads.double() ** 2).sum()))
     assert abs(gn - float(d['grad_norm'])) <= (1e-4 if f32 else 3e-2) * max(1.0, float(d['grad_norm']))
+
+
+def test_seq2seq_dropout_modes(las):
+    """decoder.dropout > 0 (asr.py:327): active in train mode (two passes differ), off in eval mode (equals the
+    dropout-0 model); encoder `dropout` is accepted and inert, as nn.LSTM(num_layers=1, dropout=p) is in the reference."""
+    ops, asr = las
+    from gen_golden import TINY
+    import copy
+    cfg = copy.deepcopy(TINY['loc_ctc'])
+    cfg['decoder']['dropout'] = 0.25
+    cfg['encoder']['dropout'] = '0.2_0.2'
+    d = np.load(os.path.join(GOLDEN, 'g3_step_loc_ctc.npz'))
+    x = torch.tensor(d['x'], device=DEV); y = torch.tensor(d['y'], device=DEV)
+    ops.set_precision('f32')
+    try:
+        m = asr.Seq2Seq(x, int(d['V']), cfg, device=DEV)
+        m.load_reference_state({k[2:]: d[k] for k in d.files if k.startswith('w.')})
+        L = int((y != 0).sum(-1).max())
+        m.train()
+        a1 = m(x, L, tf_rate=1.0, teacher=y)[2].detach().cpu().numpy()
+        a2 = m(x, L, tf_rate=1.0, teacher=y)[2].detach().cpu().numpy()
+        m.eval()
+        a3 = m(x, L, tf_rate=1.0, teacher=y)[2].detach().cpu().numpy()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    assert np.abs(a1 - a2).max() > 1e-3
+    np.testing.assert_allclose(a3, d['att_pred'], atol=5e-5, rtol=1e-3)

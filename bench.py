@@ -84,7 +84,7 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
                        f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
 
 
-PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_kernel', 'gemm': 'gemm_kernel<0, true, true',
+PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_', 'gemm': 'gemm_kernel<0, true, true',
             'vgg_fwd': 'conv_fwd_kernel<0, 2, 0>', 'vgg_bwd': 'conv_wgrad_kernel'}
 
 

@@ -15,19 +15,30 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# (flag, default, type, what it does) -- the reference's command-line surface
+FLAGS = (
+    ('--config', None, str, 'YAML with the asr_model / solver sections'),
+    ('--name', None, str, 'run name (default: <config stem>_sd<seed>)'),
+    ('--logdir', 'log/', str, 'where scalars / tensorboard events go'),
+    ('--ckpdir', 'result/', str, 'where checkpoints and decode outputs go'),
+    ('--load', None, str, 'checkpoint to resume from'),
+    ('--seed', 0, int, 'seed of Python / numpy / torch RNGs'),
+    ('--njobs', 1, int, 'accepted for compatibility (the beam is batched on the device)'),
+)
+SWITCHES = (
+    ('--cpu', 'refused: there is no CPU path in this build'),
+    ('--test', 'beam-search decoding of the test set (Tester)'),
+    ('--no-msg', 'quiet'),
+    ('--rnnlm', 'refused: the RNN-LM is out of scope'),
+)
+
+
 def parse(argv=None):
-    ap = argparse.ArgumentParser(description='Training E2E asr.')
-    ap.add_argument('--config', type=str, help='Path to experiment config.')
-    ap.add_argument('--name', default=None, type=str, help='Name for logging.')
-    ap.add_argument('--logdir', default='log/', type=str, help='Logging path.')
-    ap.add_argument('--ckpdir', default='result/', type=str, help='Checkpoint/Result path.')
-    ap.add_argument('--load', default=None, type=str, help='Load pre-trained model')
-    ap.add_argument('--seed', default=0, type=int, help='Random seed for reproducable results.')
-    ap.add_argument('--njobs', default=1, type=int, help='Number of threads for decoding.')
-    ap.add_argument('--cpu', action='store_true', help='Disable GPU training.')
-    ap.add_argument('--test', action='store_true', help='Test the model.')
-    ap.add_argument('--no-msg', action='store_true', help='Hide all messages.')
-    ap.add_argument('--rnnlm', action='store_true', help='Option for training RNNLM.')
+    ap = argparse.ArgumentParser(description='LAS training / decoding on MI355X')
+    for flag, default, typ, what in FLAGS:
+        ap.add_argument(flag, default=default, type=typ, help=what)
+    for flag, what in SWITCHES:
+        ap.add_argument(flag, action='store_true', help=what)
     a = ap.parse_args(argv)
     a.gpu, a.verbose = not a.cpu, not a.no_msg
     return a
@@ -42,16 +53,11 @@ def main(argv=None):
     torch.manual_seed(paras.seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(paras.seed)
-    if paras.rnnlm:
-        from src.solver import RNNLM_Trainer as Solver
-    elif paras.test:
-        from src.solver import Tester as Solver
-    else:
-        from src.solver import Trainer as Solver
-    solver = Solver(config, paras)
-    solver.load_data()
-    solver.set_model()
-    solver.exec()
+    import src.solver as S
+    kind = S.RNNLM_Trainer if paras.rnnlm else (S.Tester if paras.test else S.Trainer)
+    solver = kind(config, paras)
+    for stage in (solver.load_data, solver.set_model, solver.exec):
+        stage()
     return solver
 
 

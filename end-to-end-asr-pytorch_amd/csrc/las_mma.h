@@ -59,6 +59,8 @@ struct las_skinny_pw {
     float* dgates;                        // [B][4C] out
 };
 
+__device__ __forceinline__ float fast_sig(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+
 inline int las_pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
 
 #define LAS_NB_SWITCH(NBV, CALL)                        \

@@ -78,13 +78,14 @@ __device__ __forceinline__ void stage_block(T* __restrict__ tile, int ld, int dc
 // requested at kernel entry so that their memory round trip overlaps the weight stream instead of following the
 // reduction barrier.
 struct SkinnyPre { float bias[4]; float old; float pw[4]; };
-template <int NWAVES>
+template <int NWAVES, int MODE = -1>
 __device__ __forceinline__ SkinnyPre skinny_prefetch(const SkinnyArgs& a, int blk) {
+    const int mode = MODE >= 0 ? (MODE == 0 ? (a.mode & 1) : MODE) : a.mode;      // MODE 0 covers store (0) and tanh (1)
     SkinnyPre p;
     p.bias[0] = p.bias[1] = p.bias[2] = p.bias[3] = 0.f; p.old = 0.f;
     const int e = threadIdx.x;
     p.pw[0] = p.pw[1] = p.pw[2] = p.pw[3] = 0.f;
-    if (a.mode == 3) {
+    if (mode == 3) {
         const int b = min(e >> 4, a.B - 1), n = min(blk * 16 + (e & 15), a.N - 1);
         const long i = (long)b * a.N + n;
         const float* g = a.pw_gates + (long)b * 4 * a.N;
@@ -92,7 +93,7 @@ __device__ __forceinline__ SkinnyPre skinny_prefetch(const SkinnyArgs& a, int bl
         for (int q = 0; q < 4; ++q) p.bias[q] = g[q * a.N + n];                 // i, f, g, o of the earlier step
         p.old = a.pw_dh_ext[(long)b * a.pw_ld_ext + n];
         p.pw[0] = a.pw_c_t[i]; p.pw[1] = a.pw_c_prev[i]; p.pw[2] = a.pw_dc_carry[i];
-    } else if (a.mode != 2) {
+    } else if (mode != 2) {
         const int b = min(e >> 4, a.B - 1), n = min(blk * 16 + (e & 15), a.N - 1);
         if (a.bias0) p.bias[0] = a.bias0[n];
         if (a.bias1) p.bias[0] += a.bias1[n];
@@ -109,8 +110,11 @@ __device__ __forceinline__ SkinnyPre skinny_prefetch(const SkinnyArgs& a, int bl
     return p;
 }
 
-template <int NB, int NWAVES>
+// MODE >= 0 compiles only that epilogue into the kernel: these kernels are launch-bound and their duration follows their
+// code size, so an instantiation per mode is worth more than one generic body.
+template <int NB, int NWAVES, int MODE = -1>
 __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float* __restrict__ Gl, int blk, const SkinnyPre& pre0) {
+    const int mode = MODE >= 0 ? (MODE == 0 ? (a.mode & 1) : MODE) : a.mode;
     auto gsum = [&](int b, int c) -> float {
         float v = 0.f;
 #pragma unroll
@@ -118,11 +122,11 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
         return v;
     };
     auto wrow = [&](int c) -> int {
-        if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
+        if (mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
         const int n = blk * 16 + c;
         return n < a.N ? n : -1;
     };
-    if (a.mode == 3) {
+    if (mode == 3) {
         for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
             const int b = e >> 4, c = e & 15, n = wrow(c);
             if (n < 0) continue;
@@ -134,7 +138,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
             const float dh = (first ? pre0.old : a.pw_dh_ext[(long)b * a.pw_ld_ext + n]) + gsum(b, c);
             const float ct = first ? pre0.pw[0] : a.pw_c_t[i], cp = first ? pre0.pw[1] : a.pw_c_prev[i];
             const float dcc = first ? pre0.pw[2] : a.pw_dc_carry[i];
-            const float tc = tanhf(ct);
+            const float tc = fast_tanh(ct);
             const float dc = dh * og * (1.f - tc * tc) + dcc;
             float* d = a.pw_dgates + (long)b * 4 * a.N;
             d[n] = dc * gg * ig * (1.f - ig);
@@ -143,7 +147,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
             d[3 * a.N + n] = dh * tc * og * (1.f - og);
             a.pw_dc_carry[i] = dc * fg;
         }
-    } else if (a.mode != 2) {
+    } else if (mode != 2) {
         for (int e = threadIdx.x; e < a.B * 16; e += NWAVES * 64) {
             const int b = e >> 4, c = e & 15, row = wrow(c);
             if (row < 0) continue;
@@ -157,7 +161,7 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
                 if (a.bias1) v += a.bias1[row];
                 if (a.accumulate) v += *o;
             }
-            if (a.mode == 1) v = tanhf(v);
+            if (mode == 1) v = fast_tanh(v);
             *o = v;
         }
     } else {
@@ -178,11 +182,11 @@ __device__ __forceinline__ void skinny_epilogue(const SkinnyArgs& a, const float
                 }
                 pre[g] = v;
             }
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            const float ig = fast_sig(pre[0]), fg = fast_sig(pre[1]), gg = fast_tanh(pre[2]), og = fast_sig(pre[3]);
             const float cp = first ? pre0.old : a.c_prev[(long)b * a.C + u];
             const float cn = fg * cp + ig * gg;
             a.c_out[(long)b * a.C + u] = cn;
-            a.h_out[(long)b * a.C + u] = og * tanhf(cn);
+            a.h_out[(long)b * a.C + u] = og * fast_tanh(cn);
             float* go = a.gates_out + (long)b * 4 * a.C;
             go[u] = ig; go[a.C + u] = fg; go[2 * a.C + u] = gg; go[3 * a.C + u] = og;
         }
@@ -253,17 +257,17 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs a, int KC, int NC
 // segment to start 16-byte aligned with K_s % 4 == 0 (each lane's two float4 halves are either inside or outside).
 // bf16 only: lane (fr = lane&15, fq = lane>>4) holds k = 32*ks + 8*fq + {0..7} of row fr.
 // DW = waves per workgroup: 16 for NB <= 2, fewer for more batch tiles (register budget per wave)
-template <int NB, int DW>
+template <int NB, int DW, int MODE>
 __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
     __shared__ float Gl[DW * NB * 16 * 17];
     const int blk = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     auto wrow = [&](int c) -> int {
-        if (a.mode == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
+        if (MODE == 2) { const int u = blk * 4 + (c & 3); return u < a.C ? (c >> 2) * a.C + u : -1; }
         const int n = blk * 16 + c;
         return n < a.N ? n : -1;
     };
     const int row = wrow(fr);
-    const SkinnyPre pre0 = skinny_prefetch<DW>(a, blk);
+    const SkinnyPre pre0 = skinny_prefetch<DW, MODE>(a, blk);
     f32x4 acc[NB];
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -281,41 +285,47 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { nks_s[i] = i < a.ns ? (a.seg[i].K + 31) / 32 : 0; cum[i + 1] = cum[i] + nks_s[i]; }
     const int total = cum[3];
-    constexpr int U = 3;
-    for (int g0 = wave; g0 < total; g0 += U * DW) {
-        float4 bw[U][2], ax[U][NB][2];
-        bool okw[U][2], oka[U][2];
+    // A ROLLED, software-pipelined loop: the operands of k-step g + DW are requested before the MFMAs of k-step g, so
+    // two round trips overlap while the body stays ~1 KB (an unrolled three-k-step body was slower: code size).
+    struct Frag { float4 bw[2]; float4 ax[NB][2]; bool okw[2], oka[2]; };
+    auto load = [&](Frag& f, int g) {
+        const int gc = min(g, total - 1);
+        const int si = gc >= cum[2] ? 2 : (gc >= cum[1] ? 1 : 0);
+        const Seg& sg = a.seg[si];
+        const int k = (gc - cum[si]) * 32 + fq * 8, kmax = sg.K - 4;
+        const bool live = g < total;
+        f.oka[0] = live && k < sg.K;
+        f.oka[1] = live && k + 4 < sg.K;
+        f.okw[0] = f.oka[0] && row >= 0;
+        f.okw[1] = f.oka[1] && row >= 0;
+        const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
+        f.bw[0] = ldg4(wp + min(k, kmax));
+        f.bw[1] = ldg4(wp + min(k + 4, kmax));
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int g = g0 + DW * u, gc = min(g, total - 1);
-            const int si = gc >= cum[2] ? 2 : (gc >= cum[1] ? 1 : 0);
-            const Seg& sg = a.seg[si];
-            const int k = (gc - cum[si]) * 32 + fq * 8, kmax = sg.K - 4;
-            const bool live = g < total;
-            oka[u][0] = live && k < sg.K;
-            oka[u][1] = live && k + 4 < sg.K;
-            okw[u][0] = oka[u][0] && row >= 0;
-            okw[u][1] = oka[u][1] && row >= 0;
-            const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
-            bw[u][0] = ldg4(wp + min(k, kmax));
-            bw[u][1] = ldg4(wp + min(k + 4, kmax));
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                const int b = min(bt * 16 + fr, a.B - 1);
-                const float* xp = sg.x + (long)b * sg.ldx;
-                ax[u][bt][0] = ldg4(xp + min(k, kmax));
-                ax[u][bt][1] = ldg4(xp + min(k + 4, kmax));
-            }
+        for (int bt = 0; bt < NB; ++bt) {
+            const int b = min(bt * 16 + fr, a.B - 1);
+            const float* xp = sg.x + (long)b * sg.ldx;
+            f.ax[bt][0] = ldg4(xp + min(k, kmax));
+            f.ax[bt][1] = ldg4(xp + min(k + 4, kmax));
         }
+    };
+    auto mma = [&](const Frag& f) {
+        const bf16x8 bf = pack(sel4(f.okw[0], f.bw[0]), sel4(f.okw[1], f.bw[1]));
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bf16x8 bf = pack(sel4(okw[u][0], bw[u][0]), sel4(okw[u][1], bw[u][1]));
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                const bool okb = bt * 16 + fr < a.B;
-                acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    pack(sel4(okb && oka[u][0], ax[u][bt][0]), sel4(okb && oka[u][1], ax[u][bt][1])), bf, acc[bt], 0, 0, 0);
-            }
+        for (int bt = 0; bt < NB; ++bt) {
+            const bool okb = bt * 16 + fr < a.B;
+            acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                pack(sel4(okb && f.oka[0], f.ax[bt][0]), sel4(okb && f.oka[1], f.ax[bt][1])), bf, acc[bt], 0, 0, 0);
+        }
+    };
+    if (wave < total) {
+        Frag cur, nxt;
+        load(cur, wave);
+#pragma unroll 1
+        for (int g = wave; g < total; g += DW) {
+            load(nxt, g + DW);                            // (clamped, zeroed on the data when past the end)
+            mma(cur);
+            cur = nxt;
         }
     }
 #pragma unroll
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
-    skinny_epilogue<NB, DW>(a, Gl, blk, pre0);
+    skinny_epilogue<NB, DW, MODE>(a, Gl, blk, pre0);
 }
 
 constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU
@@ -384,7 +394,9 @@ int las_skinny_launch_pw(int prec, const float* x0, long ldx0, const float* w0, 
         }
         if (ok) {
             const int grid_d = mode == 2 ? (C + 3) / 4 : (N + 15) / 16;
-            LAS_NB_SWITCH(NB, { constexpr int DW_ = NB_ <= 2 ? 16 : (NB_ == 4 ? 8 : 4); hipLaunchKernelGGL((skinny_direct_kernel<NB_, DW_>), dim3(grid_d), dim3(DW_ * 64), 0, st, a); LAS_LAUNCH_OK(); return LAS_OK; });
+#define LAS_SKD_GO(M_) LAS_NB_SWITCH(NB, { constexpr int DW_ = NB_ <= 2 ? 16 : (NB_ == 4 ? 8 : 4); hipLaunchKernelGGL((skinny_direct_kernel<NB_, DW_, M_>), dim3(grid_d), dim3(DW_ * 64), 0, st, a); LAS_LAUNCH_OK(); return LAS_OK; })
+            if (a.mode == 2) { LAS_SKD_GO(2); } else if (a.mode == 3) { LAS_SKD_GO(3); } else { LAS_SKD_GO(0); }
+#undef LAS_SKD_GO
         }
     }
     int KC = 0, NCK = 0;

@@ -296,8 +296,9 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
     for (int t = 0; t < L; ++t) {
         const float* h0_prev = s.hs + (long)t * BC;                           // layer 0, slot t = h_{t-1}
         float* q_t = s.q + (long)t * B * A;
-        int rc = las_skinny_launch(prec, h0_prev, C, p->w_phi, C, C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0,
-                                   B, A, nullptr, nullptr, 1, q_t, A, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
+        int rc = las_skinny_launch_pk(prec, h0_prev, C, p->w_phi, C, C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0,
+                                      B, A, nullptr, nullptr, 1, q_t, A, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      p->pk_phi, st);
         if (rc) return rc;
         AttArgs a{};
         a.B = B; a.Tp = Tp; a.E = E; a.A = A; a.loc = loc; a.TC = TC;
@@ -359,9 +360,10 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
                 hp = hd;
             }
             const float* cp = s.cs + ((long)l * (L + 1) + t) * BC;
-            rc = las_skinny_launch(prec, x, Kx, p->w_ih[l], Kx, Kx, hp, C, p->w_hh[l], C, C, nullptr, 0, nullptr, 0, 0, B, 4 * C,
-                                   p->b_ih[l], p->b_hh[l], 2, nullptr, 0, 0, C, cp, s.hs + ((long)l * (L + 1) + t + 1) * BC,
-                                   s.cs + ((long)l * (L + 1) + t + 1) * BC, s.gates + ((long)l * L + t) * B * 4 * C, st);
+            rc = las_skinny_launch_pk(prec, x, Kx, p->w_ih[l], Kx, Kx, hp, C, p->w_hh[l], C, C, nullptr, 0, nullptr, 0, 0, B, 4 * C,
+                                      p->b_ih[l], p->b_hh[l], 2, nullptr, 0, 0, C, cp, s.hs + ((long)l * (L + 1) + t + 1) * BC,
+                                      s.cs + ((long)l * (L + 1) + t + 1) * BC, s.gates + ((long)l * L + t) * B * 4 * C, nullptr,
+                                      p->pk_cell[l], st);
             if (rc) return rc;
         }
     }

@@ -17,12 +17,6 @@ int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, lon
                       long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
                       float* gates_out, hipStream_t st);
 
-int las_skinny_launch_pw(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
-                         long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
-                         long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
-                         long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
-                         float* gates_out, const las_skinny_pw* pw, hipStream_t st);
-
 namespace {
 
 constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;
@@ -498,8 +492,9 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             }
             const int Kx = l == 0 ? (int)XI : C;
             float* dx = l == 0 ? w.dxin + (long)t * B * XI : w.d_below;
-            int rc = las_skinny_launch(prec, dg, 4 * C, p->w_ihT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr,
-                                       0, 0, B, Kx, nullptr, nullptr, 0, dx, Kx, 0, 0, nullptr, nullptr, nullptr, nullptr, st);
+            int rc = las_skinny_launch_pk(prec, dg, 4 * C, p->w_ihT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr,
+                                          0, 0, B, Kx, nullptr, nullptr, 0, dx, Kx, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          p->pk_dx[l], st);
             if (rc) return rc;
             if (drop && l == 0) {                      // d xin = d(xdrop) * mask of the forward pass
                 rc = las_dropout_rows(dx, Kx, dx, Kx, B, Kx, d->dropout, las_decoder_drop_seed(d->drop_seed, t, 0), stream);
@@ -508,9 +503,9 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
             // recurrent carry dh_{l,t-1} = dgates * W_hh; layer 0 gets the attention-query path in the same product
             // (second k-segment dq_pre_t * W_phi) and is therefore launched after the attention backward below
             if (l > 0 && t > 0) {
-                rc = las_skinny_launch(prec, dg, 4 * C, p->w_hhT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0,
-                                       0, B, C, nullptr, nullptr, 0, w.dh_carry + (long)l * BC, C, 0, 0, nullptr, nullptr, nullptr,
-                                       nullptr, st);
+                rc = las_skinny_launch_pk(prec, dg, 4 * C, p->w_hhT[l], 4 * C, 4 * C, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0,
+                                          0, B, C, nullptr, nullptr, 0, w.dh_carry + (long)l * BC, C, 0, 0, nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, p->pk_dh[l], st);
                 if (rc) return rc;
                 if (drop) {                            // layer l >= 1 saw dropout(h_{l,t-1}) as its recurrent state
                     rc = las_dropout_rows(w.dh_carry + (long)l * BC, C, w.dh_carry + (long)l * BC, C, B, C, d->dropout,
@@ -562,9 +557,9 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
                 pw.gates = s.gates + (long)(t - 1) * B * 4 * C; pw.c_t = s.cs + (long)t * BC; pw.c_prev = s.cs + (long)(t - 1) * BC;
                 pw.dgates = w.dgates + (long)(t - 1) * B * 4 * C;
             }
-            int rc = las_skinny_launch_pw(prec, dg0, 4 * C, p->w_hhT[0], 4 * C, 4 * C, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A,
+            int rc = las_skinny_launch_pk(prec, dg0, 4 * C, p->w_hhT[0], 4 * C, 4 * C, w.dq_pre + (long)t * B * A, A, p->w_phiT, A, A,
                                           nullptr, 0, nullptr, 0, 0, B, C, nullptr, nullptr, 0, w.dh_carry, C, 0, 0, nullptr, nullptr,
-                                          nullptr, nullptr, fuse_pw ? &pw : nullptr, st);
+                                          nullptr, nullptr, fuse_pw ? &pw : nullptr, p->pk_dh[0], st);
             if (rc) return rc;
         }
     }

@@ -61,6 +61,12 @@ struct las_skinny_pw {
 
 __device__ __forceinline__ float fast_sig(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
 
+int las_skinny_launch_pk(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                         long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                         long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                         long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                         float* gates_out, const las_skinny_pw* pw, const void* wpk, hipStream_t st);
+
 inline int las_pick_nb(int B) { return B <= 16 ? 1 : B <= 32 ? 2 : B <= 64 ? 4 : B <= 128 ? 8 : 0; }
 
 #define LAS_NB_SWITCH(NBV, CALL)                        \

@@ -34,6 +34,10 @@ struct SkinnyArgs {
     // dh_ext it goes straight through that step's cell pointwise backward (decoder_bwd.hip cell_pw_bwd) for element (b,n)
     const float* pw_dh_ext; long pw_ld_ext; float* pw_dc_carry; const float* pw_gates; const float* pw_c_t;
     const float* pw_c_prev; float* pw_dgates;
+    // optional: the weight operand pre-packed in MFMA fragment order (las_skinny_pack_weights): for block b and k-step g
+    // (over the concatenated segments) 64 lanes x 8 bf16 contiguous, i.e. ONE fully coalesced 1 KB read per wave and
+    // k-step instead of two 16-byte pieces from each of 16 rows 4*K bytes apart; zero where the row or k is out of range
+    const bf16_t* wpk;
 };
 
 // Stage `nrows` rows x n columns (fp32 source, row r at base + rowidx(r)*ldsrc) into tile[r][dcol..dcol+n) with all
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
     // A ROLLED, software-pipelined loop: the operands of k-step g + DW are requested before the MFMAs of k-step g, so
     // two round trips overlap while the body stays ~1 KB (an unrolled three-k-step body was slower: code size).
     struct Frag { float4 bw[2]; float4 ax[NB][2]; bool okw[2], oka[2]; };
+    const bool packed = a.wpk != nullptr;
     auto load = [&](Frag& f, int g) {
         const int gc = min(g, total - 1);
         const int si = gc >= cum[2] ? 2 : (gc >= cum[1] ? 1 : 0);
@@ -298,9 +303,13 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         f.oka[1] = live && k + 4 < sg.K;
         f.okw[0] = f.oka[0] && row >= 0;
         f.okw[1] = f.oka[1] && row >= 0;
-        const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
-        f.bw[0] = ldg4(wp + min(k, kmax));
-        f.bw[1] = ldg4(wp + min(k + 4, kmax));
+        if (packed) {
+            f.bw[0] = ldg4((const float*)(a.wpk + (((long)blk * total + gc) * 64 + lane) * 8));
+        } else {
+            const float* __restrict__ wp = sg.w + (long)rowc * sg.ldw;
+            f.bw[0] = ldg4(wp + min(k, kmax));
+            f.bw[1] = ldg4(wp + min(k + 4, kmax));
+        }
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
             const int b = min(bt * 16 + fr, a.B - 1);
@@ -310,7 +319,8 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         }
     };
     auto mma = [&](const Frag& f) {
-        const bf16x8 bf = pack(sel4(f.okw[0], f.bw[0]), sel4(f.okw[1], f.bw[1]));
+        // (a packed fragment needs no mask: it is zero where it must be, and a k-step past the end meets zeroed A)
+        const bf16x8 bf = packed ? __builtin_bit_cast(bf16x8, f.bw[0]) : pack(sel4(f.okw[0], f.bw[0]), sel4(f.okw[1], f.bw[1]));
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
             const bool okb = bt * 16 + fr < a.B;
@@ -334,6 +344,25 @@ __global__ __launch_bounds__(DW * 64) void skinny_direct_kernel(SkinnyArgs a) {
         for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
     __syncthreads();
     skinny_epilogue<NB, DW, MODE>(a, Gl, blk, pre0);
+}
+
+// grid (blocks of 16 output rows, k-steps), 64 threads: lane (fr, fq) converts W[row(fr)][k0 + 8 fq .. +7] of its segment
+__global__ __launch_bounds__(64) void skinny_pack_kernel(SkinnyArgs a, int total, bf16_t* __restrict__ out) {
+    const int blk = blockIdx.x, g = blockIdx.y, lane = threadIdx.x, fr = lane & 15, fq = lane >> 4;
+    int row;
+    if (a.mode == 2) { const int u = blk * 4 + (fr & 3); row = u < a.C ? (fr >> 2) * a.C + u : -1; }
+    else { const int n = blk * 16 + fr; row = n < a.N ? n : -1; }
+    int cum[4];
+    cum[0] = 0;
+    for (int i = 0; i < 3; ++i) cum[i + 1] = cum[i] + (i < a.ns ? (a.seg[i].K + 31) / 32 : 0);
+    const int si = g >= cum[2] ? 2 : (g >= cum[1] ? 1 : 0);
+    const Seg& sg = a.seg[si];
+    const int k = (g - cum[si]) * 32 + fq * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (row >= 0 && k + j < sg.K) ? sg.w[(long)row * sg.ldw + k + j] : 0.f;
+    const u32x4 r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    *(u32x4*)(out + (((long)blk * total + g) * 64 + lane) * 8) = r;
 }
 
 constexpr size_t SKINNY_LDS_TARGET = 72 * 1024;      // keep >= 2 workgroups per CU
@@ -369,7 +398,17 @@ int las_skinny_launch_pw(int prec, const float* x0, long ldx0, const float* w0, 
                          long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
                          long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
                          float* gates_out, const las_skinny_pw* pw, hipStream_t st) {
+    return las_skinny_launch_pk(prec, x0, ldx0, w0, ldw0, K0, x1, ldx1, w1, ldw1, K1, x2, ldx2, w2, ldw2, K2, B, N, bias0, bias1,
+                                mode, out, ldo, accumulate, C, c_prev, h_out, c_out, gates_out, pw, nullptr, st);
+}
+
+int las_skinny_launch_pk(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
+                         long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,
+                         long ldw2, int K2, int B, int N, const float* bias0, const float* bias1, int mode, float* out,
+                         long ldo, int accumulate, int C, const float* c_prev, float* h_out, float* c_out,
+                         float* gates_out, const las_skinny_pw* pw, const void* wpk, hipStream_t st) {
     SkinnyArgs a{};
+    a.wpk = prec == LAS_PREC_BF16 ? (const bf16_t*)wpk : nullptr;
     a.seg[0] = Seg{x0, ldx0, w0, ldw0, K0};
     a.seg[1] = Seg{x1, ldx1, w1, ldw1, K1};
     a.seg[2] = Seg{x2, ldx2, w2, ldw2, K2};
@@ -431,4 +470,29 @@ extern "C" int las_skinny_linear(int prec, const float* x, int64_t ldx, const fl
     return las_skinny_launch(prec, x, ldx, w, ldw, K, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, B, N, bias,
                              nullptr, act ? 1 : 0, out, ldo, accumulate, 0, nullptr, nullptr, nullptr, nullptr,
                              (hipStream_t)stream);
+}
+
+// ---- pre-packed weight operand (bf16 mode): same segment list / row mapping as the product that will read it
+extern "C" size_t las_skinny_pack_bytes(int N, int K0, int K1, int K2, int cell_mode, int C) {
+    const long nblk = cell_mode ? (C + 3) / 4 : (N + 15) / 16;
+    const long total = (K0 + 31) / 32 + (K1 > 0 ? (K1 + 31) / 32 : 0) + (K2 > 0 ? (K2 + 31) / 32 : 0);
+    return (size_t)(nblk * total * 64 * 8 * sizeof(bf16_t));
+}
+
+extern "C" int las_skinny_pack_weights(const float* w0, int64_t ldw0, int K0, const float* w1, int64_t ldw1, int K1,
+                                       const float* w2, int64_t ldw2, int K2, int N, int cell_mode, int C, void* out,
+                                       void* stream) {
+    LAS_CHECK_ARG(w0 && out && K0 > 0 && N > 0 && (!cell_mode || (C > 0 && N == 4 * C)));
+    SkinnyArgs a{};
+    a.seg[0] = Seg{nullptr, 0, w0, ldw0, K0};
+    a.seg[1] = Seg{nullptr, 0, w1, ldw1, w1 ? K1 : 0};
+    a.seg[2] = Seg{nullptr, 0, w2, ldw2, w2 ? K2 : 0};
+    a.ns = w2 ? 3 : (w1 ? 2 : 1);
+    a.N = N; a.C = C; a.mode = cell_mode ? 2 : 0;
+    const int nblk = cell_mode ? (C + 3) / 4 : (N + 15) / 16;
+    int total = 0;
+    for (int i = 0; i < a.ns; ++i) total += (a.seg[i].K + 31) / 32;
+    hipLaunchKernelGGL(skinny_pack_kernel, dim3(nblk, total), dim3(64), 0, (hipStream_t)stream, a, total, (bf16_t*)out);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
 }

@@ -17,7 +17,8 @@ class DecDims(ctypes.Structure):
 class DecParams(ctypes.Structure):
     _fields_ = [('emb', P), ('w_phi', P), ('conv_w', P), ('w_lp', P), ('w_e', P), ('b_e', P),
                 ('w_ih', P * 4), ('w_hh', P * 4), ('b_ih', P * 4), ('b_hh', P * 4), ('w_char', P), ('b_char', P),
-                ('w_ihT', P * 4), ('w_hhT', P * 4), ('w_phiT', P)]
+                ('w_ihT', P * 4), ('w_hhT', P * 4), ('w_phiT', P),
+                ('pk_phi', P), ('pk_cell', P * 4), ('pk_dx', P * 4), ('pk_dh', P * 4)]
 
 
 class DecState(ctypes.Structure):
@@ -29,9 +30,30 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def make_params(W, NL, loc, transposed=None):
-    """W: dict of contiguous fp32 HIP tensors with the reference's parameter names."""
+USE_PACKED = True     # bf16 mode: weight operands of the per-step products pre-packed in MFMA fragment order
+
+
+def pack_weights(ws, N, cell_C=0):
+    """ws: up to three [N, K_i] fp32 HIP matrices (the k-segments of one skinny product) -> packed bf16 operand."""
+    L_ = _lib.lib()
+    ws = [w.contiguous() for w in ws] + [None] * (3 - len(ws))
+    K = [int(w.shape[1]) if w is not None else 0 for w in ws]
+    nbytes = L_.las_skinny_pack_bytes(I(N), I(K[0]), I(K[1]), I(K[2]), I(1 if cell_C else 0), I(cell_C))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=ws[0].device)
+    LL = ctypes.c_int64
+    check(L_.las_skinny_pack_weights(ptr(ws[0]), LL(K[0]), I(K[0]), ptr(ws[1]), LL(K[1]), I(K[1]), ptr(ws[2]), LL(K[2]), I(K[2]),
+                                     I(N), I(1 if cell_C else 0), I(cell_C), P(out.data_ptr()), cur_stream()), 'las_skinny_pack_weights')
+    return out
+
+
+def make_params(W, NL, loc, transposed=None, packed=None):
+    """W: dict of contiguous fp32 HIP tensors with the reference's parameter names.  packed: dict of pack_weights()
+    results under 'phi', 'cell{l}', 'dx{l}', 'dh{l}' (optional)."""
     p = DecParams()
+    if packed:
+        p.pk_phi = _p(packed.get('phi'))
+        for l in range(NL):
+            p.pk_cell[l], p.pk_dx[l], p.pk_dh[l] = _p(packed.get(f'cell{l}')), _p(packed.get(f'dx{l}')), _p(packed.get(f'dh{l}'))
     p.emb, p.w_phi = _p(W['embed.weight']), _p(W['attention.phi.weight'])
     if loc:
         p.conv_w, p.w_lp = _p(W['attention.loc_conv.weight']), _p(W['attention.loc_proj.weight'])
@@ -81,8 +103,14 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
     A = psi.shape[-1]
     V, C = W['embed.weight'].shape
     dims = DecDims(B, Tp, E, A, C, NL, V, L, int(loc), ops._prec, float(dropout), int(drop_seed) & 0xffffffff)
-    params = make_params(W, NL, loc)
+    packed = None
+    if ops._prec == 0 and USE_PACKED:
+        packed = {'phi': pack_weights([W['attention.phi.weight']], A)}
+        for l in range(NL):
+            packed[f'cell{l}'] = pack_weights([W[f'decoder.layer{l}.weight_ih'], W[f'decoder.layer{l}.weight_hh']], 4 * C, cell_C=C)
+    params = make_params(W, NL, loc, packed=packed)
     S, st = alloc_state(dims, enc.device)
+    S['_packed'] = packed
     sm = None
     if step_mode is not None:
         sm = (ctypes.c_uint8 * L)(*[int(v) for v in step_mode])
@@ -158,7 +186,13 @@ class DecoderFn(torch.autograd.Function):
         for l in range(NL):
             tr[f'ih{l}'] = transpose2d(W[f'decoder.layer{l}.weight_ih'])
             tr[f'hh{l}'] = transpose2d(W[f'decoder.layer{l}.weight_hh'])
-        params = make_params(W, NL, loc, tr)
+        packed = None
+        if S.get('_packed') is not None:
+            packed = {}
+            for l in range(NL):
+                packed[f'dx{l}'] = pack_weights([tr[f'ih{l}']], int(tr[f'ih{l}'].shape[0]))
+                packed[f'dh{l}'] = pack_weights([tr[f'hh{l}']] + ([tr['phi']] if l == 0 else []), C)
+        params = make_params(W, NL, loc, tr, packed=packed)
         nch = L_.las_decoder_att_chunks(I(Tp))
         accf = L_.las_decoder_loc_acc_floats(I(A))
         Bw = dict(dgates=torch.empty(NL, L, B, 4 * C, **f32), dxin=torch.empty(L, B, C + E, **f32),

@@ -131,6 +131,12 @@ typedef struct {
     const float* w_ihT[4];          /* [C+E | C][4C] */
     const float* w_hhT[4];          /* [C][4C] */
     const float* w_phiT;            /* [C][A] */
+    /* optional (bf16 mode): the weight operand of each M = batch product pre-packed in MFMA fragment order by
+       las_skinny_pack_weights (one coalesced 1 KB read per wave and k-step); NULL: read the matrices above */
+    const void* pk_phi;             /* N = A: w_phi */
+    const void* pk_cell[4];         /* cell l: N = 4C (cell_mode), segments w_ih[l], w_hh[l] */
+    const void* pk_dx[4];           /* N = C+E | C: w_ihT[l] */
+    const void* pk_dh[4];           /* N = C: w_hhT[l] (l = 0: segments w_hhT[0], w_phiT) */
 } las_dec_params;
 typedef struct {                    /* saved activations, written by fwd, read by bwd (caller-owned) */
     int32_t* tok;                   /* [L][B] token fed at each step */
@@ -209,6 +215,13 @@ int las_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, f
                   const float* norm3, const int32_t* step_dev, int zero_grad, void* stream);
 int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps,
                       const float* norm3, int zero_grad, void* stream);
+
+/* Weight operand of a skinny product (las_skinny_linear / las_lstm_cell_fwd / the decoder's per-step products) packed as
+ * bf16 MFMA fragments: for every block of 16 output rows and every 32-wide k-step over the concatenated segments,
+ * 64 lanes x 8 values; cell_mode: rows are the gate-interleaved rows of las_lstm_cell_fwd (N = 4C). */
+size_t las_skinny_pack_bytes(int N, int K0, int K1, int K2, int cell_mode, int C);
+int las_skinny_pack_weights(const float* w0, int64_t ldw0, int K0, const float* w1, int64_t ldw1, int K1,
+                            const float* w2, int64_t ldw2, int K2, int N, int cell_mode, int C, void* out, void* stream);
 
 /* inverted dropout on rows: out[r][i] = keep ? in[r][i] / (1-p) : 0, keep = hash(seed, r*N+i) >= p (nn.Dropout at
  * asr.py:327; same distribution, not torch's stream).  in == out allowed.  las_decoder_drop_seed: the seed the decoder

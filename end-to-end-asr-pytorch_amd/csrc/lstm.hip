@@ -198,26 +198,25 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
                                        : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 
-    // ---- my pointwise elements: pairs (b, n..n+1); eb = row within the slice
-    constexpr int PP = (NB * 16 * 8 + NT - 1) / NT;
-    const int half = U / 2;
-    float c_state[PP][2];
-    float bias[PP][4][2];
-    int eb[PP], en[PP];
-    bool ev[PP];
+    // ---- my pointwise elements: ONE (batch row, unit) per thread and 256-element pass (NB passes): the cell update is
+    // VALU-issue bound with one wave per SIMD (five v_exp/v_rcp chains per element), so it is spread over all the
+    // lanes the slice can fill (12 rows x 16 units = waves 0-2; the polling wave stays free when Bs <= 12)
+    constexpr int PE = NB;
+    float c_state[PE];
+    float bias[PE][4];
+    int eb[PE], en[PE];
+    bool ev[PE];
 #pragma unroll
-    for (int p = 0; p < PP; ++p) {
+    for (int p = 0; p < PE; ++p) {
         const int e = threadIdx.x + p * NT;
-        eb[p] = e / half; en[p] = (e % half) * 2;
-        ev[p] = (e < NB * 16 * half) && eb[p] < Bl && (j0 + en[p] < H);
-        c_state[p][0] = c_state[p][1] = 0.f;
+        eb[p] = e >> 4; en[p] = e & 15;
+        ev[p] = eb[p] < Bl && en[p] < U && (j0 + en[p] < H);
+        c_state[p] = 0.f;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int j = j0 + en[p] + q;
-                bias[p][gi][q] = (ev[p] && j < H) ? b_ih[d * 4 * H + gi * H + j] + b_hh[d * 4 * H + gi * H + j] : 0.f;
-            }
+        for (int gi = 0; gi < 4; ++gi) {
+            const int j = j0 + en[p];
+            bias[p][gi] = ev[p] ? b_ih[d * 4 * H + gi * H + j] + b_hh[d * 4 * H + gi * H + j] : 0.f;
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * 4 * H;
@@ -227,13 +226,12 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         const int t = d == 0 ? s : a.T - 1 - s;
         const int tp = d == 0 ? t - 1 : t + 1;
         // (a) prefetch x-projection of my elements (independent of the recurrence)
-        float2 xp[PP][4];
+        float xp[PE][4];
 #pragma unroll
-        for (int p = 0; p < PP; ++p)
+        for (int p = 0; p < PE; ++p)
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                xp[p][gi] = ev[p] ? *(const float2*)(xproj + ((long)t * B + b0 + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p])
-                                  : make_float2(0.f, 0.f);
+                xp[p][gi] = ev[p] ? xproj[((long)t * B + b0 + eb[p]) * ND4H + d * 4 * H + gi * H + j0 + en[p]] : 0.f;
         // (b,c) wait for h_{t-1} of every unit of my direction, pull it into LDS
         f32x4 acc[NB];
 #pragma unroll
@@ -272,47 +270,43 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
             for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
         __syncthreads();
         // (f) pointwise cell update; publish h_t FIRST, signal, then write what only the backward pass reads
-        float hv[PP][2], gv[PP][4][2];
+        float hv[PE], gv[PE][4];
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
-            if (!ev[p]) continue;
-            const int bl = eb[p], n = en[p], j = j0 + n;
-            const bool m = t < lensl[bl];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float pi = Gl[(0 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][0].y : xp[p][0].x) + bias[p][0][q];
-                const float pf = Gl[(1 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][1].y : xp[p][1].x) + bias[p][1][q];
-                const float pg = Gl[(2 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][2].y : xp[p][2].x) + bias[p][2][q];
-                const float po = Gl[(3 * NB * 16 + bl) * 17 + n + q] + (q ? xp[p][3].y : xp[p][3].x) + bias[p][3][q];
-                const float ig = fsig(pi), fg = fsig(pf), gg = ftanh(pg), og = fsig(po);
-                const float cn = fg * c_state[p][q] + ig * gg;
-                const float hn = og * ftanh(cn);
-                const bool mq = m && (j + q < H);
-                c_state[p][q] = mq ? cn : c_state[p][q];
-                hv[p][q] = mq ? hn : 0.f;
-                gv[p][0][q] = mq ? ig : 0.f; gv[p][1][q] = mq ? fg : 0.f; gv[p][2][q] = mq ? gg : 0.f; gv[p][3][q] = mq ? og : 0.f;
-            }
-            st_pair_sc1(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p][0], hv[p][1]);
+        for (int p = 0; p < PE; ++p) {
+            const int bl = min(eb[p], NB * 16 - 1), n = en[p], j = j0 + n;
+            const bool mq = ev[p] && t < lensl[bl];
+            const float pi = Gl[(0 * NB * 16 + bl) * 17 + n] + xp[p][0] + bias[p][0];
+            const float pf = Gl[(1 * NB * 16 + bl) * 17 + n] + xp[p][1] + bias[p][1];
+            const float pg = Gl[(2 * NB * 16 + bl) * 17 + n] + xp[p][2] + bias[p][2];
+            const float po = Gl[(3 * NB * 16 + bl) * 17 + n] + xp[p][3] + bias[p][3];
+            const float ig = fsig(pi), fg = fsig(pf), gg = ftanh(pg), og = fsig(po);
+            const float cn = fg * c_state[p] + ig * gg;
+            const float hn = og * ftanh(cn);
+            c_state[p] = mq ? cn : c_state[p];
+            hv[p] = mq ? hn : 0.f;
+            gv[p][0] = mq ? ig : 0.f; gv[p][1] = mq ? fg : 0.f; gv[p][2] = mq ? gg : 0.f; gv[p][3] = mq ? og : 0.f;
+            // the unit pair (n, n+1) goes out as one store from the even lane; its partner's h comes over DPP (row_shl:1)
+            const float hnext = las_dpp<0x101, 0xf>(0.f, hv[p]);
+            if (ev[p] && !(n & 1)) st_pair_sc1(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p], hnext);
         }
         // (g) publish: only the exchange stores are outstanding here
         block_signal(cnt);
         if (a.dbg & 8) continue;
 #pragma unroll
-        for (int p = 0; p < PP; ++p) {
+        for (int p = 0; p < PE; ++p) {
             if (!ev[p]) continue;
             const int bl = eb[p], b = b0 + bl, j = j0 + en[p];
             const bool m = t < lensl[bl];
             const long ro = (long)t * B + b;
-            *(float2*)(hf + ro * (ND * H) + d * H + j) = make_float2(hv[p][0], hv[p][1]);
+            hf[ro * (ND * H) + d * H + j] = hv[p];
             if (!a.y_is_hf) {
                 bool ok;
                 const long yo = y_offset(a, t, b, d, j, ok);
-                if (ok) *(float2*)(y + yo) = make_float2(hv[p][0], hv[p][1]);
+                if (ok) y[yo] = hv[p];
             }
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi)
-                *(float2*)(gates + ro * ND4H + d * 4 * H + gi * H + j) = make_float2(gv[p][gi][0], gv[p][gi][1]);
-            *(float2*)(cs + ro * (ND * H) + d * H + j) = make_float2(m ? c_state[p][0] : 0.f, m ? c_state[p][1] : 0.f);
+            for (int gi = 0; gi < 4; ++gi) gates[ro * ND4H + d * 4 * H + gi * H + j] = gv[p][gi];
+            cs[ro * (ND * H) + d * H + j] = m ? c_state[p] : 0.f;
         }
     }
 }

@@ -549,35 +549,49 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
         float dh_rec[2] = {0.f, 0.f};
         if (s > 0) {
             if (!block_wait(cnt, (unsigned)G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
-            pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, WPT, WPT, 0, Pl, WPT);
+            // (only the Bl batch rows of each piece that carry data are pulled)
+            pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, (Bl * WPR + 3) & ~3, WPT, 0, Pl, WPT);
             __syncthreads();
-            if (ev) {                                     // sum of the G pieces, four independent chains
-                float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ev) {                                     // sum of the G pieces: every LDS read is issued before the first add
                 const unsigned* pw = Pl + eb * WPR + (PREC == LAS_PREC_BF16 ? en / 2 : en);
-                int p = 0;
-                for (; p + 3 < G; p += 4) {
+                float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+                if (PREC == LAS_PREC_BF16 && MT == 5 && G > 10) {      // (measured: pays for 11..20 pieces only)
+                    constexpr int NP = MT * 4;            // >= G
+                    unsigned w[NP];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if constexpr (PREC == LAS_PREC_BF16) {
-                            const unsigned w = pw[(p + u) * WPT];
-                            s0[u] += __uint_as_float(w << 16);
-                            s1[u] += __uint_as_float(w & 0xffff0000u);
-                        } else {
-                            const uint2 w = *(const uint2*)(pw + (p + u) * WPT);
-                            s0[u] += __uint_as_float(w.x);
-                            s1[u] += __uint_as_float(w.y);
+                    for (int p = 0; p < NP; ++p) w[p] = pw[min(p, G - 1) * WPT];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const unsigned v = p < G ? w[p] : 0u;
+                        s0[p & 3] += __uint_as_float(v << 16);
+                        s1[p & 3] += __uint_as_float(v & 0xffff0000u);
+                    }
+                } else {
+                    int p = 0;
+                    for (; p + 3 < G; p += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if constexpr (PREC == LAS_PREC_BF16) {
+                                const unsigned w = pw[(p + u) * WPT];
+                                s0[u] += __uint_as_float(w << 16);
+                                s1[u] += __uint_as_float(w & 0xffff0000u);
+                            } else {
+                                const uint2 w = *(const uint2*)(pw + (p + u) * WPT);
+                                s0[u] += __uint_as_float(w.x);
+                                s1[u] += __uint_as_float(w.y);
+                            }
                         }
                     }
-                }
-                for (; p < G; ++p) {
-                    if constexpr (PREC == LAS_PREC_BF16) {
-                        const unsigned w = pw[p * WPT];
-                        s0[0] += __uint_as_float(w << 16);
-                        s1[0] += __uint_as_float(w & 0xffff0000u);
-                    } else {
-                        const uint2 w = *(const uint2*)(pw + p * WPT);
-                        s0[0] += __uint_as_float(w.x);
-                        s1[0] += __uint_as_float(w.y);
+                    for (; p < G; ++p) {
+                        if constexpr (PREC == LAS_PREC_BF16) {
+                            const unsigned w = pw[p * WPT];
+                            s0[0] += __uint_as_float(w << 16);
+                            s1[0] += __uint_as_float(w & 0xffff0000u);
+                        } else {
+                            const uint2 w = *(const uint2*)(pw + p * WPT);
+                            s0[0] += __uint_as_float(w.x);
+                            s1[0] += __uint_as_float(w.y);
+                        }
                     }
                 }
                 dh_rec[0] = (s0[0] + s0[1]) + (s0[2] + s0[3]);

@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void att_softmax_ctx(int Tp, int E, const floa
                                                        float* __restrict__ att_out, float* __restrict__ ctx_out,
                                                        long ld_ctx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* a_l = sm;                 // [Tp]
-    float* red = sm + Tp;            // [32]
-    float* part = red + 32;          // [4][64]
+    float* a_l = sm;                 // [Tp] (padded to 4)
+    float* red = sm + ((Tp + 3) & ~3);   // [32]
+    float* part = red + 32;          // [16][64]
     const int b = blockIdx.y, len = lens[b];
     float m = -INFINITY;
     for (int i = threadIdx.x; i < len; i += 256) { const float v = ATT_SCALE * e[(long)b * Tp + i]; a_l[i] = v; m = fmaxf(m, v); }
@@ -193,6 +193,43 @@ __global__ __launch_bounds__(256) void att_softmax_ctx(int Tp, int E, const floa
         if (blockIdx.x == 0) att_out[(long)b * Tp + i] = v;
     }
     __syncthreads();
+    // context for my 64 columns: thread = (column quad, one of 16 time groups); 8 independent 16-byte loads in flight
+    // per thread (the 4-deep, one-column-per-thread form spent ~19 dependent round trips on T' = 300)
+    const bool vec = (E & 3) == 0 && ((((uintptr_t)enc) & 15) == 0);
+    if (vec) {
+        const int cq = threadIdx.x & 15, tg = threadIdx.x >> 4, col = blockIdx.x * 64 + cq * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < E) {
+            const float* __restrict__ p = enc + (long)b * Tp * E + col;
+            int t = tg;
+            for (; t + 7 * 16 < len; t += 8 * 16) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(p + (long)(t + 16 * u) * E);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float w = a_l[t + 16 * u];
+                    acc.x += w * v[u].x; acc.y += w * v[u].y; acc.z += w * v[u].z; acc.w += w * v[u].w;
+                }
+            }
+            for (; t < len; t += 16) {
+                const float4 v = *(const float4*)(p + (long)t * E);
+                const float w = a_l[t];
+                acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+            }
+        }
+        float* part4 = part;                             // [16][64] (the caller sizes the region for it)
+        *(float4*)(part4 + tg * 64 + cq * 4) = acc;
+        __syncthreads();
+        const int c = threadIdx.x;
+        if (c < 64 && blockIdx.x * 64 + c < E) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += part4[g * 64 + c];
+            ctx_out[(long)b * ld_ctx + blockIdx.x * 64 + c] = sum;
+        }
+        return;
+    }
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), tg = threadIdx.x >> 6;
     float acc = 0.f;
     if (col < E) {
@@ -291,7 +328,7 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
     size_t lds_e = sizeof(float) * (size_t)A;
     if (loc) lds_e = sizeof(float) * ((size_t)2 * A + LOC_C * A + LOC_C * LOC_W + TC + 2 * LOC_K + 2 * LOC_C * TC);
     if (lds_e > 64 * 1024) return LAS_E_UNSUPPORTED;
-    const size_t lds_s = sizeof(float) * ((size_t)Tp + 32 + 256);
+    const size_t lds_s = sizeof(float) * (((size_t)Tp + 3) / 4 * 4 + 32 + 1024);
     if (lds_s > 64 * 1024) return LAS_E_UNSUPPORTED;
     for (int t = 0; t < L; ++t) {
         const float* h0_prev = s.hs + (long)t * BC;                           // layer 0, slot t = h_{t-1}

@@ -185,7 +185,7 @@ def main():
     note(f'{dt * 1e3 / a.steps:.1f} ms/step; kernel timing pass')
     # ---- roofline of the dominant kernel: live HIP-event timing of its launches over 3 more steps
     # The brackets are HIP events on the launch stream, so a bracket also counts any time the GPU waits for the host
-    # to enqueue the next kernel.  Each timed step therefore starts with a ~25 ms device-side sleep: the host (≈14 ms
+    # to enqueue the next kernel.  Each timed step therefore starts with a ~25 ms device-side sleep: the host (≈6 ms
     # of enqueue work per step) gets a full step ahead and the brackets see back-to-back kernels, as in the timed
     # loop above and in the rocprofv3 trace.
     run(a.warmup + a.steps, 1, known_lengths=True)

@@ -34,3 +34,20 @@ if os.environ.get('LAS_HOST_PROFILE'):
     st = pstats.Stats(pr)
     st.sort_stats('tottime').print_stats(28)
     st.sort_stats('cumulative').print_stats(40)
+# ---- pure host cost: enqueue one step while the GPU is parked in a device-side sleep (nothing can block on a full queue)
+if hasattr(torch.cuda, '_sleep'):
+    import cProfile, pstats
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(4):
+        torch.cuda._sleep(400_000_000)        # ~0.2 s
+        t0 = time.perf_counter()
+        t.train_step(x, y, 1.0, host_lens=hl)
+        ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    print('pure host enqueue per step (GPU parked): ' + ', '.join(f'{1e3*v:.1f} ms' for v in ts))
+    torch.cuda._sleep(400_000_000)
+    pr = cProfile.Profile(); pr.enable()
+    t.train_step(x, y, 1.0, host_lens=hl)
+    pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(14)

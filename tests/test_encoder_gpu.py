@@ -122,3 +122,51 @@ def test_infer_lengths_and_transpose(ops):
     np.testing.assert_array_equal(ops.transpose01(xg).cpu().numpy(), x.transpose(1, 0, 2))
     y = torch.tensor([[0, 3, 4, 1, 0], [0, 2, 1, 0, 0]], device=DEV)
     assert ops.count_nonzero(y).cpu().tolist() == [3, 2]
+
+
+@pytest.mark.parametrize('T,B,Iin,H,prec', [(25, 100, 16, 64, 'f32'), (19, 130, 16, 320, 'f32'), (15, 300, 8, 256, 'f32'),
+                                             (21, 24, 16, 512, 'bf16'), (12, 30, 8, 40, 'f32'), (15, 300, 8, 320, 'bf16')])
+def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):
+    """The launch geometries beyond the C2 shape: many batch slices (B=100), two batch tiles per slice (B=130 at H=320),
+    four (B=300 at H=256: LDS-resident weights forward, all-gather backward), H=512 (8-unit workgroups forward, 32 pieces in the
+    K-split backward), H not a multiple of 16.  Against the oracle (torch packed LSTM), ragged lengths; f32 mode where its
+    LDS-resident f32 weight slab fits (H < ~500 at one batch tile, H <= 256 at four), bf16 mode (8e-2 / 5e-2) otherwise."""
+    from oracle import las_ref as R
+    rng = np.random.RandomState(T * 1000 + B)
+    lens = sorted(rng.randint(max(1, T // 3), T + 1, size=B).tolist(), reverse=True); lens[0] = T
+    x = np.zeros((B, T, Iin), np.float32)
+    for b, l in enumerate(lens):
+        x[b, :l] = rng.randn(l, Iin)
+    W = {}
+    for sfx in ['', '_reverse']:
+        W['L.layer.weight_ih_l0' + sfx] = torch.tensor((rng.randn(4 * H, Iin) / np.sqrt(Iin)).astype(np.float32), requires_grad=True)
+        W['L.layer.weight_hh_l0' + sfx] = torch.tensor((rng.randn(4 * H, H) / np.sqrt(H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_ih_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_hh_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+    xr = torch.tensor(x, requires_grad=True)
+    yr, olen = R.rnn_layer(xr, lens, W, 'L', 1, 'concat', True, fast=True)
+    gy = rng.randn(*yr.shape).astype(np.float32)
+    (yr * torch.tensor(gy)).sum().backward()
+    dd = {k[len('L.layer.'):]: v.detach().numpy() for k, v in W.items()}
+    gd = {k[len('L.layer.'):]: v.grad.numpy() for k, v in W.items()}
+    w_ih, w_hh, b_ih, b_hh = [T_(v, True) for v in cat_lstm_weights(dd, '', True)]
+    xg = T_(x, True)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.set_precision(prec)
+    try:
+        y = ops.Transpose01Fn.apply(ops.lstm_layer(ops.Transpose01Fn.apply(xg), torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                                   w_ih, w_hh, b_ih, b_hh, 1, True, status))
+        (y * T_(gy)).sum().backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    assert int(status.item()) == 0
+    tol = dict(atol=2e-4, rtol=1e-3) if prec == 'f32' else dict(atol=8e-2, rtol=5e-2)
+    close(y, yr.detach().numpy(), tol)
+    close(xg.grad, xr.grad.numpy(), tol)
+    g_ih, g_hh, g_bi, g_bh = cat_lstm_weights(gd, '', True)
+    scale = max(1.0, np.abs(g_hh).max(), np.abs(g_ih).max())
+    close(w_ih.grad / scale, g_ih / scale, tol)
+    close(w_hh.grad / scale, g_hh / scale, tol)
+    close(b_ih.grad / scale, g_bi / scale, tol)

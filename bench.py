@@ -37,6 +37,10 @@ WORKLOADS = {
     'c5': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
                enc=('320_320_320_320_320', '1_1_1_1_1'), enc_type='VGGBiRNN', style='drop', att=('loc', 300), dec=320,
                name='config/libri_example.yaml: VGGBiRNN (VGG front-end + 5x320 BiLSTM), loc-attn, CTC 0.5, V=5000, bf16'),
+    # stress shape, not a headline: the same config at its `max_timestep: 3000` / `max_label_len: 400` limits
+    'c6': dict(D=80, V=5000, B=24, T_max=3000, L_max=400, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+               enc=('320_320_320_320_320', '1_1_1_1_1'), enc_type='VGGBiRNN', style='drop', att=('loc', 300), dec=320,
+               name='config/libri_example.yaml at max_timestep 3000 / max_label_len 400 (stress shape)'),
 }
 
 

@@ -78,6 +78,7 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
     W = {k: (torch.randn(s) / max(1.0, (s[1] if len(s) > 1 else 1) ** 0.5)).numpy() if len(s) > 1 else torch.zeros(s).numpy()
          for k, s in shapes.items()}
     ref = R.RefTrainStep(W, cfg, fast=True)
+    ref.step(x[:1].numpy(), y[:1].numpy())   # untimed: thread pool / allocator warm-up on one utterance
     t0 = time.time()
     for _ in range(steps):
         ref.step(x.numpy(), y.numpy())
@@ -119,7 +120,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-b', type=int, default=2)
+    ap.add_argument('--cpu-sample-b', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     cfg = model_cfg(w)
@@ -216,7 +218,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             note('cpu baseline (oracle on host cores)')
-            out['cpu_baseline'] = cpu_baseline(w, cfg, a.cpu_sample_b)
+            out['cpu_baseline'] = cpu_baseline(w, cfg, a.cpu_sample_b, a.cpu_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -120,49 +120,87 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
     float att_r[ATT_ROWS];
 #pragma unroll
     for (int r = 0; r < ATT_ROWS; ++r) att_r[r] = a.att[(long)b * a.Tp + min(t0 + wave + ATT_NW * r, t0 + tcv - 1)];
-    // ---- staging + the softmax dot
+    // ---- staging + the softmax dot.  EVERY global load of this section is issued before the first LDS store: section
+    // by section (load, wait, store) it was seven dependent memory round trips queued behind the row prefetch above --
+    // 11-15 k of the kernel's ~42 k cycles (cycle stamps).  Loads are unconditional from clamped indices.
     float part = 0.f;
-    for (int i = threadIdx.x; i < a.E; i += ATT_NT) {
-        const float d = a.dctx[(long)b * a.ld_dctx + i];
-        dctx_l[i] = d;
-        part += d * a.ctx[(long)b * a.ld_ctx + i];
-    }
     const bool carry = LOC && a.df_next != nullptr;
+    constexpr int NE = 2;                                            // E <= 1024
+    constexpr int NWLP = (LOC_C * 64 * AI + ATT_NT - 1) / ATT_NT;    // A <= 64 AI
+    constexpr int NCW = (LOC_C * LOC_W + ATT_NT - 1) / ATT_NT;
+    constexpr int HU = (LOC_C * (20 + 2 * LOC_K) + ATT_NT - 1) / ATT_NT;       // chunks are <= 20 frames
+    constexpr int NDOT = 6;                                          // first 6 * 512 elements of <df_next, f_next>
+    float d_r[NE], c_r[NE], we_r = 0.f, wlp_r[LOC ? NWLP : 1], f_r = 0.f, cw_r[LOC ? NCW : 1], hv[LOC ? HU : 1];
+    float dn_r[LOC ? NDOT : 1], fn_r[LOC ? NDOT : 1];
+    const int tid = threadIdx.x;
+    const float* __restrict__ dn = LOC && carry ? a.df_next + (long)b * LOC_C * a.Tp : nullptr;
+    const float* __restrict__ fn = LOC && carry ? a.f_next + (long)b * LOC_C * a.Tp : nullptr;
+    const int ndot = LOC_C * a.Tp;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int i = min(tid + ATT_NT * u, a.E - 1);
+        d_r[u] = a.dctx[(long)b * a.ld_dctx + i];
+        c_r[u] = a.ctx[(long)b * a.ld_ctx + i];
+    }
     if (LOC) {
-        fill_batched<2>(a.w_e, a.A, [&](int i, float v) { we_l[i] = v; });
-        fill_batched<8>(a.w_lp, LOC_C * a.A, [&](int i, float v) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = v; });
-        const float* __restrict__ fp = a.f + (long)b * LOC_C * a.Tp;
-        for (int i = threadIdx.x; i < LOC_C * a.TC; i += ATT_NT) {
-            const int c = i / a.TC, tt = i - c * a.TC;
-            const float v = fp[(long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
-            f_l[i] = (tt < tcv) ? v : 0.f;
+        we_r = a.w_e[min(tid, a.A - 1)];
+#pragma unroll
+        for (int u = 0; u < NWLP; ++u) wlp_r[u] = a.w_lp[min(tid + ATT_NT * u, LOC_C * a.A - 1)];
+        {
+            const int i = min(tid, LOC_C * a.TC - 1), c = i / a.TC, tt = i - c * a.TC;
+            f_r = a.f[(long)b * LOC_C * a.Tp + (long)c * a.Tp + min(t0 + tt, a.Tp - 1)];
         }
         if (carry) {
-            fill_batched<8>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { cw_l[i] = v; });
-            const float* __restrict__ dn = a.df_next + (long)b * LOC_C * a.Tp;
-            const float* __restrict__ fn = a.f_next + (long)b * LOC_C * a.Tp;
-            constexpr int HU = (LOC_C * (20 + 2 * LOC_K) + ATT_NT - 1) / ATT_NT;       // chunks are <= 20 frames
-            float hv[HU];
 #pragma unroll
-            for (int u = 0; u < HU; ++u) {           // all halo loads in flight before the first LDS store
-                const int i = min((int)threadIdx.x + ATT_NT * u, LOC_C * W - 1);
+            for (int u = 0; u < NCW; ++u) cw_r[u] = a.conv_w[min(tid + ATT_NT * u, LOC_C * LOC_W - 1)];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const int i = min(tid + ATT_NT * u, LOC_C * W - 1);
                 const int c = i / W, j = i - c * W, t = t0 - LOC_K + j;
                 const float v = dn[(long)c * a.Tp + min(max(t, 0), a.Tp - 1)];
                 hv[u] = (t >= 0 && t < a.Tp) ? v : 0.f;
             }
 #pragma unroll
+            for (int u = 0; u < NDOT; ++u) {
+                const int i = min(tid + ATT_NT * u, ndot - 1);
+                dn_r[u] = dn[i]; fn_r[u] = fn[i];
+            }
+        }
+    }
+    // ---- now the LDS stores and the dot partials
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int i = tid + ATT_NT * u;
+        if (i < a.E) { dctx_l[i] = d_r[u]; part += d_r[u] * c_r[u]; }
+    }
+    for (int i = tid + ATT_NT * NE; i < a.E; i += ATT_NT) {          // (E > 1024)
+        const float d = a.dctx[(long)b * a.ld_dctx + i];
+        dctx_l[i] = d;
+        part += d * a.ctx[(long)b * a.ld_ctx + i];
+    }
+    if (LOC) {
+        if (tid < a.A) we_l[tid] = we_r;
+#pragma unroll
+        for (int u = 0; u < NWLP; ++u) {
+            const int i = tid + ATT_NT * u;
+            if (i < LOC_C * a.A) { const int aa = i / LOC_C, c = i - aa * LOC_C; wlp_l[c * a.A + aa] = wlp_r[u]; }
+        }
+        if (tid < LOC_C * a.TC) { const int tt = tid % a.TC; f_l[tid] = (tt < tcv) ? f_r : 0.f; }
+        if (carry) {
+#pragma unroll
+            for (int u = 0; u < NCW; ++u) {
+                const int i = tid + ATT_NT * u;
+                if (i < LOC_C * LOC_W) cw_l[i] = cw_r[u];
+            }
+#pragma unroll
             for (int u = 0; u < HU; ++u) {
-                const int i = threadIdx.x + ATT_NT * u;
+                const int i = tid + ATT_NT * u;
                 if (i < LOC_C * W) dfh_l[i] = hv[u];
             }
-            const int n = LOC_C * a.Tp;                                      // <df_next, f_next>
-            int i = threadIdx.x;
-            for (; i + 3 * ATT_NT < n; i += 4 * ATT_NT) {
-                const float d0 = dn[i], d1 = dn[i + ATT_NT], d2 = dn[i + 2 * ATT_NT], d3 = dn[i + 3 * ATT_NT];
-                const float f0 = fn[i], f1 = fn[i + ATT_NT], f2 = fn[i + 2 * ATT_NT], f3 = fn[i + 3 * ATT_NT];
-                part += d0 * f0 + d1 * f1 + d2 * f2 + d3 * f3;
-            }
-            for (; i < n; i += ATT_NT) part += dn[i] * fn[i];
+#pragma unroll
+            for (int u = 0; u < NDOT; ++u)
+                if (tid + ATT_NT * u < ndot) part += dn_r[u] * fn_r[u];
+            for (int i = tid + ATT_NT * NDOT; i < ndot; i += ATT_NT) part += dn[i] * fn[i];     // (T' > 307)
         }
     }
     const float dot = block_sum(part, red);          // (its barriers also publish the LDS staging)

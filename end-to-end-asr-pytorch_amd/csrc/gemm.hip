@@ -22,16 +22,28 @@ template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                   long lda, long sA, const float* __restrict__ B, long ldb, long sB,
                                                   float beta, float* __restrict__ C, long ldc, long sC,
-                                                  const float* __restrict__ bias, int act, int ksplit) {
+                                                  const float* __restrict__ bias, int act, int ksplit, int swz) {
     typedef typename Elem<PREC>::T T;
     constexpr int LD = BK + Elem<PREC>::PAD;
     __shared__ __attribute__((aligned(16))) T As2[2][BM * LD];      // double buffered: one barrier per k-tile
     __shared__ __attribute__((aligned(16))) T Bs2[2][BN * LD];
 
     // blockIdx.z = batch index, or (ksplit > 1, batch == 1) the K-slice whose partial product is added atomically
-    const int bz = ksplit > 1 ? 0 : (int)blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so in launch order the
+    // tiles that share an A panel land in 8 different L2s and every panel is fetched 8 times.  Give the blocks that share
+    // an XCD (id % 8) one contiguous run of tiles instead (bijective for any grid size), n fastest inside the run.
+    int bx = blockIdx.x, by = blockIdx.y, bzz = blockIdx.z;
+    if (swz) {
+        const int nx = gridDim.x, nxy = nx * gridDim.y, nwg = nxy * gridDim.z;
+        const int orig = (bzz * (int)gridDim.y + by) * nx + bx;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bzz = t / nxy; t -= bzz * nxy;
+        by = t / nx; bx = t - by * nx;
+    }
+    const int bz = ksplit > 1 ? 0 : bzz;
     A += (long)bz * sA; B += (long)bz * sB; C += (long)bz * sC;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int fr = lane & 15, fq = lane >> 4;
@@ -50,7 +62,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
                                   : B + (long)((threadIdx.x >> 5) * 4) * ldb + n0 + (threadIdx.x & 31) * 4;
     const int nk_all = (K + BK - 1) / BK;
     const int per = (nk_all + ksplit - 1) / ksplit;
-    const int kt0 = ksplit > 1 ? (int)blockIdx.z * per : 0;
+    const int kt0 = ksplit > 1 ? bzz * per : 0;
     const int nk = min(nk_all, kt0 + per);
     if (kt0 >= nk) return;
     {
@@ -136,10 +148,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
 template <int PREC, bool VEC>
 int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const float* A, long lda,
            long sA, const float* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias,
-           int act, int ksplit) {
+           int act, int ksplit, int swz) {
 #define LAS_GEMM_GO(AK, BK_)                                                                                          \
     hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_, VEC>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
-                       sB, beta, C, ldc, sC, bias, act, ksplit)
+                       sB, beta, C, ldc, sC, bias, act, ksplit, swz)
     if (!ta && tb) LAS_GEMM_GO(true, true);
     else if (!ta && !tb) LAS_GEMM_GO(true, false);
     else if (ta && !tb) LAS_GEMM_GO(false, false);
@@ -205,12 +217,14 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
     const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0) && (transB ? K % 4 == 0 : N % 4 == 0);
     const bool vec = vecA && vecB && K >= 4 && M >= 4 && N >= 4;
     hipStream_t st = (hipStream_t)stream;
+    static const int swz_env = getenv("LAS_GEMM_NOSWZ") ? 0 : 1;
+    if (ksplit > 1) grid.z = ksplit;
+    const int swz = swz_env && (long)grid.x * grid.y * grid.z >= 16;
     if (ksplit > 1) {
-        grid.z = ksplit;
         hipLaunchKernelGGL(scale2d_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, beta, N, C, (long)ldc);
         LAS_LAUNCH_OK();
     }
-#define LAS_GEMM_ARGS transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit
+#define LAS_GEMM_ARGS transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit, swz
     if (prec == LAS_PREC_BF16) return vec ? launch<LAS_PREC_BF16, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_BF16, false>(LAS_GEMM_ARGS);
     return vec ? launch<LAS_PREC_F32, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_F32, false>(LAS_GEMM_ARGS);
 #undef LAS_GEMM_ARGS

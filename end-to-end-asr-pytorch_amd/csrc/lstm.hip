@@ -32,8 +32,10 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr size_t MIN_LDS = 84 * 1024;            // > 80 KiB: at most one workgroup per CU
 
 constexpr int MAX_SLICES = 16;
-constexpr int CNT_STRIDE = 64;      // words: every counter on a 256-byte line of its own (pollers of one (direction, slice)
-                                    // group must not share a line with another group's atomics)
+constexpr int CNT_STRIDE = 128;     // words per (direction, slice) group, lines of their own (pollers of one group must
+                                    // not share a line with another group's atomics): word 0 arrival counter, words 32-34
+                                    // placement rendezvous, words 64-95 per-producer progress words (L2-local mode)
+constexpr int FLAG_OFS = 64;
 struct SyncWords {          // zeroed by hipMemsetAsync before every launch
     unsigned cnt[2 * MAX_SLICES * CNT_STRIDE];   // arrivals per (direction, batch slice)
     unsigned abort_;                // set on spin timeout
@@ -66,26 +68,60 @@ __device__ __forceinline__ bool wait_counter(unsigned* cnt, unsigned target, uns
 // poll is never stuck behind a cold HBM access.
 #define LAS_SYNC_THREAD (NT - 64)
 
-// Block-wide wait: one lane polls, result broadcast through LDS word `flag`.
-__device__ __forceinline__ bool block_wait(unsigned* cnt, unsigned target, unsigned* abort_word, int* flag) {
-    if (threadIdx.x == LAS_SYNC_THREAD) *flag = wait_counter(cnt, target, abort_word) ? 1 : 0;
+// L2-local mode (the group's G <= 32 workgroups share one XCD): no atomics at all.  Producer g keeps a progress word
+// (steps published so far, a plain store that lands in the XCD's L2); the last wave polls all G words at once, lane l
+// the word of producer l, with L1-bypassing loads that hit that L2.  (An agent-scope atomic and its poll go to the
+// memory side whatever their scope bits say: 1.8 us per step for a single workgroup handing off to itself.)
+__device__ __forceinline__ bool wait_flags(unsigned* flags, int G, unsigned target, unsigned* abort_word) {
+    unsigned* p = flags + min((int)(threadIdx.x & 63), G - 1);
+    unsigned spins = 0;
+    while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            if (spins > SPIN_LIMIT) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// Block-wide wait for `steps` publications of every workgroup of the group; result broadcast through LDS word `flag`.
+__device__ __forceinline__ bool block_wait(unsigned* cnt, int G, unsigned steps, unsigned* abort_word, int* flag, bool local) {
+    if (local) {
+        if (threadIdx.x >= LAS_SYNC_THREAD) {
+            const bool ok = wait_flags(cnt + FLAG_OFS, G, steps, abort_word);
+            if (threadIdx.x == LAS_SYNC_THREAD) *flag = ok ? 1 : 0;
+        }
+    } else if (threadIdx.x == LAS_SYNC_THREAD) *flag = wait_counter(cnt, (unsigned)G * steps, abort_word) ? 1 : 0;
     __syncthreads();
     return *flag != 0;
 }
 
-// Publish: every storing wave has drained its stores; one lane signals.
-__device__ __forceinline__ void block_signal(unsigned* cnt) {
+// Publish: every storing wave has drained its stores; one lane signals (`steps` = publications so far, this one
+// included).  `local`: every workgroup of the group sits on ONE XCD, checked at run time by group_local below.
+__device__ __forceinline__ void block_signal(unsigned* cnt, bool local, int g, unsigned steps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == LAS_SYNC_THREAD) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == LAS_SYNC_THREAD) {
+        if (local) cnt[FLAG_OFS + g] = steps;
+        else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-__device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
-    __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Exchange stores.  Across XCDs every published byte is an sc1 (write-through) store; inside one XCD a plain store
+// (write-through L1, line KEPT in the shared L2) is what the consumers' L1-bypassing loads hit at L2 speed
+// (MI355X_MICROARCH.md, handoff-payload row: 104-122 vs 62-73 GB/s per block).
+__device__ __forceinline__ void st_pair_x(bf16_t* p, float a, float b, bool local) {
+    if (local) *(unsigned*)p = pack_bf16x2(a, b);
+    else __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
+__device__ __forceinline__ void st_pair_x(float* p, float a, float b, bool local) {
     const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (local) *(unsigned long long*)p = v;
+    else __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Pull a [rows x cols] tile (row stride `src_ld` elements, published by other CUs) into LDS rows of stride `ld`:
@@ -145,7 +181,52 @@ struct LstmArgs {
     int NS, Bs;               // batch slices (independent sub-recurrences) and rows per slice
     int sr, concat, T_out, F_out;
     int y_is_hf;
+    int xl;                   // XCD-grouped launch: grid = 8 * G * ceil(groups / 8), see lstm_role
 };
+
+// Which (direction d, unit slice g, batch slice bs) a workgroup works on.  A GROUP = the G workgroups of one
+// (d, bs): they exchange h / dgates every step and share a counter.  Default: consecutive ids.  xl: workgroups are
+// dealt round-robin to the 8 XCDs (ids congruent mod 8 share one: observed, not contractual), so group `grp` takes
+// ids == grp (mod 8) and all its hand-offs stay inside one XCD's L2; ids whose group does not exist exit at once.
+struct Role { int d, g, bs; bool idle; };
+__device__ __forceinline__ Role lstm_role(const LstmArgs& a) {
+    Role r;
+    const int bid = blockIdx.x;
+    if (a.xl) {
+        const int label = bid & 7, li = bid >> 3, grp = (li / a.G) * 8 + label;
+        r.g = li % a.G; r.idle = grp >= a.ND * a.NS; r.d = grp / a.NS; r.bs = grp - r.d * a.NS;
+    } else {
+        r.d = bid / (a.G * a.NS); r.g = (bid % (a.G * a.NS)) / a.NS; r.bs = bid % a.NS; r.idle = false;
+    }
+    return r;
+}
+
+// Placement is only ever a speed assumption: before the first step the G workgroups of a group meet once through the
+// placement-independent protocol (agent-scope atomics) and compare their hardware XCC ids.  1: all on one XCD -> the
+// L2-local exchange (plain stores, L2 atomics); 0: not -> the sc1 protocol; -1: timeout.  `w` = the second 128-byte
+// line of the group's counter slot (zeroed with it).
+__device__ __forceinline__ int group_local(const LstmArgs& a, unsigned* cnt, unsigned* abort_word, int* flag) {
+    if (!a.xl) return 0;
+    if (threadIdx.x == LAS_SYNC_THREAD) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 15u;
+        unsigned* w = cnt + 32;
+        const unsigned o1 = __hip_atomic_fetch_max(w + 1, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned o2 = __hip_atomic_fetch_max(w + 2, 16u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o1), "v"(o2) : "memory");          // both maxima performed before the arrival below
+        __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int r = -1;
+        if (wait_counter(w, (unsigned)a.G, abort_word))
+            r = (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                 __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 17u ? 1 : 0;
+        *flag = r;
+    }
+    __syncthreads();
+    const int r = *flag;
+    __syncthreads();
+    return r;
+}
 
 __device__ __forceinline__ long y_offset(const LstmArgs& a, int t, int b, int d, int j, bool& ok) {
     // layer output / its gradient, time-major [T_out][B][F_out]; concat: reference asr.py:493-494, drop: :491
@@ -170,7 +251,9 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     const int H = a.H, B = a.B, U = a.U, ND = a.ND;
     const int Kp = (H + KSTEP - 1) / KSTEP * KSTEP, ld = Kp + VEC;
     const int Hx = (H + VEC - 1) / VEC * VEC;           // exchange row stride (pad columns are caller-zeroed)
-    const int d = blockIdx.x / (a.G * a.NS), g = (blockIdx.x % (a.G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * U;
+    const Role role = lstm_role(a);
+    if (role.idle) return;
+    const int d = role.d, g = role.g, bs = role.bs, j0 = g * U;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);  // my batch slice: rows [b0, b0+Bl)
     T* Wl = (T*)smem;                                   // [4][16][ld]
     T* Hl = Wl + 4 * 16 * ld;                           // [NB*16][ld]
@@ -221,6 +304,9 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int ND4H = ND * 4 * H;
     unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
+    const int gl = group_local(a, cnt, &sync->abort_, flag);
+    if (gl < 0) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+    const bool local = gl == 1;
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? s : a.T - 1 - s;
@@ -237,7 +323,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             // every wave needs the whole h tile: one shared pull into LDS (a direct global->register read per wave
             // would fetch it four times through sc1 and measured slower)
             if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
@@ -287,10 +373,10 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
             gv[p][0] = mq ? ig : 0.f; gv[p][1] = mq ? fg : 0.f; gv[p][2] = mq ? gg : 0.f; gv[p][3] = mq ? og : 0.f;
             // the unit pair (n, n+1) goes out as one store from the even lane; its partner's h comes over DPP (row_shl:1)
             const float hnext = las_dpp<0x101, 0xf>(0.f, hv[p]);
-            if (ev[p] && !(n & 1)) st_pair_sc1(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p], hnext);
+            if (ev[p] && !(n & 1)) st_pair_x(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p], hnext, local);
         }
         // (g) publish: only the exchange stores are outstanding here
-        block_signal(cnt);
+        block_signal(cnt, local, g, (unsigned)s + 1u);
         if (a.dbg & 8) continue;
 #pragma unroll
         for (int p = 0; p < PE; ++p) {
@@ -326,7 +412,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     const int H = a.H, B = a.B, U = a.U, ND = a.ND, K4 = 4 * H;
     const int KC = K4p / NC;                              // chunk width; K4p = 4H zero-padded so KC % (4*KSTEP) == 0
     const int ldw = K4p + VEC, ldc = KC + VEC;
-    const int d = blockIdx.x / (a.G * a.NS), g = (blockIdx.x % (a.G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * U;
+    const Role role = lstm_role(a);
+    if (role.idle) return;
+    const int d = role.d, g = role.g, bs = role.bs, j0 = g * U;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
     T* Wl = (T*)smem;                                     // [16][ldw]   W_hh^T columns of my units
     T* Dl = Wl + 16 * ldw;                                // [NB*16][ldc] dgates_next chunk
@@ -368,6 +456,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
     const int ND4H = ND * K4, NDH = ND * H;
     unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
     const int kq = KC / KSTEP / 4;                        // k-steps per wave per chunk
+    const int gl = group_local(a, cnt, &sync->abort_, flag);
+    if (gl < 0) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+    const bool local = gl == 1;
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? a.T - 1 - s : s;           // reverse of the forward processing order
@@ -397,7 +488,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!(a.dbg & 1) && !block_wait(cnt, (unsigned)a.G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
             if constexpr (KS > 0) {
                 mma_direct<NB, KS>(acc, (const bf16_t*)src, Bl, K4, wave * KS * 32, K4 - wave * KS * 32, wfrag);
@@ -442,9 +533,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
             }
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                st_pair_sc1(dgx + (((long)d * a.T + t) * B + b0 + bl) * K4 + gi * H + j, dg[p][gi][0], dg[p][gi][1]);
+                st_pair_x(dgx + (((long)d * a.T + t) * B + b0 + bl) * K4 + gi * H + j, dg[p][gi][0], dg[p][gi][1], local);
         }
-        block_signal(cnt);
+        block_signal(cnt, local, g, (unsigned)s + 1u);
 #pragma unroll
         for (int p = 0; p < PP; ++p) {
             if (!ev[p]) continue;
@@ -482,7 +573,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
     constexpr int WPT = NB * 16 * WPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, B = a.B, ND = a.ND, K4 = 4 * H, G = a.G;
-    const int d = blockIdx.x / (G * a.NS), g = (blockIdx.x % (G * a.NS)) / a.NS, bs = blockIdx.x % a.NS, j0 = g * 16;
+    const Role role = lstm_role(a);
+    if (role.idle) return;
+    const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
     T* Wl = (T*)smem;                                     // [G*16][LDK]  W_hh[my 64 gate rows][every column], k contiguous
     T* Dl = Wl + (size_t)G * 16 * LDK;                    // [NB*16][LDK] my dgates of this step
@@ -543,12 +636,15 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
         if (ok) sdy = *(const float2*)(dy + yo);
     };
     load_inputs(0);
+    const int gl = group_local(a, cnt, &sync->abort_, flag);
+    if (gl < 0) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+    const bool local = gl == 1;
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? a.T - 1 - s : s;           // reverse of the forward processing order
         float dh_rec[2] = {0.f, 0.f};
         if (s > 0) {
-            if (!block_wait(cnt, (unsigned)G * s, &sync->abort_, flag)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!block_wait(cnt, G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             // (only the Bl batch rows of each piece that carry data are pulled)
             pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, (Bl * WPR + 3) & ~3, WPT, 0, Pl, WPT);
             __syncthreads();
@@ -651,8 +747,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
                         if (row < Bl) {
                             const unsigned long long v = (unsigned long long)pack_bf16x2(acc[0], acc[1]) |
                                                          ((unsigned long long)pack_bf16x2(acc[2], acc[3]) << 32);
-                            __hip_atomic_store((unsigned long long*)(dst + row * WPR + fq * 2), v, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                            if (local) *(unsigned long long*)(dst + row * WPR + fq * 2) = v;
+                            else __hip_atomic_store((unsigned long long*)(dst + row * WPR + fq * 2), v, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
@@ -668,12 +765,13 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
                             const u32x4 v = {__float_as_uint(acc[0][0]), __float_as_uint(acc[0][1]), __float_as_uint(acc[0][2]),
                                              __float_as_uint(acc[0][3])};
                             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, WPT * 4, 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * WPR + fq * 4) * 4, 0, 16);
+                            if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * WPR + fq * 4) * 4, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * WPR + fq * 4) * 4, 0, 16);
                         }
                     }
                 }
             }
-            block_signal(cnt);
+            block_signal(cnt, local, g, (unsigned)s + 1u);
         }
         // fp32 copy for the weight-gradient GEMMs, then next step's inputs
         if (ev) {
@@ -733,7 +831,12 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
     a.y_is_hf = 0;
     { static const char* e = getenv("LAS_DBG_LSTM"); a.dbg = e ? atoi(e) : 0; }
+    // XCD-grouped launch when every XCD (32 CUs, one workgroup per CU) can hold the groups dealt to it
+    static const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
+    const int groups = ND * a.NS, gpl = (groups + 7) / 8;
+    a.xl = (!no_xl && a.G * gpl <= 32) ? 1 : 0;
 }
+int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
 
 template <int PREC, int NB, int KS>
 int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
@@ -741,7 +844,7 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
                SyncWords* sync, int* status) {
     auto k = lstm_fwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (typename CT<PREC>::T*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
@@ -752,7 +855,7 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
                int* status) {
     auto k = lstm_bwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
+    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), lds, st, a, NC, K4p, dy, gates, cs, w_hh, lens,
                        (typename CT<PREC>::T*)dgx, dgf, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
@@ -844,7 +947,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     {                                                                                                                 \
         auto k = lstm_bwd_ks_kernel<P_, N_, M_>;                                                                      \
         LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));            \
-        hipLaunchKernelGGL(k, dim3(a.ND * a.G * a.NS), dim3(NT), l2, st, a, dy, gates, cs, w_hh, lens, (unsigned*)dgx, dgf, \
+        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), l2, st, a, dy, gates, cs, w_hh, lens, (unsigned*)dgx, dgf, \
                            (SyncWords*)sync, status);                                                                 \
         LAS_LAUNCH_OK();                                                                                              \
         return LAS_OK;                                                                                                \

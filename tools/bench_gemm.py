@@ -1,26 +1,47 @@
-"""Per-shape GEMM timing at the config-C2 shapes (fwd NT, dgrad NN, wgrad TN)."""
-import importlib, sys, torch
-sys.path.insert(0, '.')
-importlib.import_module('end-to-end-asr-pytorch_amd')
+#!/usr/bin/env python
+"""Times las_gemm (through the C ABI) on the GEMM shapes of the c2 training step -- the x*W_ih^T projections of the five
+BiLSTM layers, their dX and dW products -- and prints TFLOP/s per shape.  GPU only."""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
-dev = 'cuda:0'
-ops.set_precision(sys.argv[1] if len(sys.argv) > 1 else 'bf16')
-shapes = [  # (name, M, N, K)
-    ('L0 xproj', 28800, 2560, 80), ('L1 xproj', 14400, 2560, 1280), ('L2 xproj', 7200, 2560, 1280), ('L3 xproj', 7200, 2560, 640),
-    ('L0 proj', 14400, 1280, 1280), ('L1 proj', 7200, 1280, 1280), ('L2 proj', 7200, 640, 640), ('psi', 7200, 300, 640),
-    ('char', 3600, 31, 320), ('sq4096', 4096, 4096, 4096)]
-tot = {}
-for name, M, N, K in shapes:
-    X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); dY = torch.randn(M, N, device=dev)
-    for tag, fn, fl in [('fwd  NT', lambda: ops.gemm(X, W, transB=True), 2 * M * N * K),
-                        ('dgrad NN', lambda: ops.gemm(dY, W), 2 * M * N * K),
-                        ('wgrad TN', lambda: ops.gemm(dY, X, transA=True), 2 * M * N * K)]:
-        for _ in range(2): fn()
+
+B = 24
+SHAPES = []   # (tag, transA, transB, M, N, K)
+for tag, T, I in (('l0', 1200, 80), ('l1', 600, 1280), ('l2', 300, 1280), ('l3', 300, 640)):
+    SHAPES.append((f'{tag} xproj  A*B^T', False, True, T * B, 2560, I))
+    if tag != 'l0':
+        SHAPES.append((f'{tag} dX     A*B  ', False, False, T * B, I, 2560))
+    SHAPES.append((f'{tag} dW_ih  A^T*B', True, False, 2560, I, T * B))
+    SHAPES.append((f'{tag} dW_hh  A^T*B', True, False, 1280, 320, T * B))
+
+
+def main():
+    dev = torch.device('cuda:0')
+    ops.set_precision('bf16') if hasattr(ops, 'set_precision') else None
+    reps = int(os.environ.get('REPS', 10))
+    for tag, ta, tb, M, N, K in SHAPES:
+        A = torch.randn((K, M) if ta else (M, K), device=dev)
+        Bm = torch.randn((N, K) if tb else (K, N), device=dev)
+        C = torch.empty(M, N, device=dev)
+        for _ in range(2):
+            ops.gemm(A, Bm, C, transA=ta, transB=tb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
         e0.record()
-        for _ in range(5): fn()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        tot[tag] = tot.get(tag, 0) + ms
-        print(f'{name:10s} {tag} M={M:6d} N={N:5d} K={K:5d}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s', flush=True)
-print(tot)
+        for _ in range(reps):
+            ops.gemm(A, Bm, C, transA=ta, transB=tb)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() if M * N * K < 2e10 else None
+        err = '' if ref is None else f'  rel.err {float((C.double() - ref).abs().max() / ref.abs().max()):.1e}'
+        print(f'{tag:20s} M={M:6d} N={N:5d} K={K:6d}  {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s{err}', flush=True)
+
+
+if __name__ == '__main__':
+    main()

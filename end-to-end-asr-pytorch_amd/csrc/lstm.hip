@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
         if (s > 0) {
             if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             // every wave needs the whole h tile: one shared pull into LDS (a direct global->register read per wave
-            // would fetch it four times through sc1 and measured slower)
+            // fetches it four times in fragment-shaped pieces: slower across XCDs, and 2.9 vs 2.06 us inside one)
             if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
             __syncthreads();
             // (d) gate pre-activations: wave w <-> gate w
@@ -891,9 +891,12 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     int U = 16;
     if (ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
     // use more, smaller unit slices when the chip has room (shorter MFMA chains per step)
-    if (ND * ((H + 7) / 8) <= 256 && H >= 512) U = 8;
     LstmArgs a;
     fill_args(a, T, B, H, ND, U, sr, concat);
+    if (!a.xl && ND * ((H + 7) / 8) <= 256 && H >= 512) {      // (an XCD-grouped launch beats the finer slicing)
+        U = 8;
+        fill_args(a, T, B, H, ND, U, sr, concat);
+    }
     const int NB = las_pick_nb(a.Bs);
     if (NB == 0) return LAS_E_UNSUPPORTED;
     size_t lds = fwd_lds(prec, H, NB);

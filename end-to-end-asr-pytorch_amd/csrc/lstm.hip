@@ -645,6 +645,30 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
         float dh_rec[2] = {0.f, 0.f};
         if (s > 0) {
             if (!block_wait(cnt, G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            bool direct_sum = false;
+            if constexpr (PREC == LAS_PREC_BF16 && MT <= 8) direct_sum = local && !(a.dbg & 16);
+            if (direct_sum) {
+                // L2-local group: each pointwise thread reads its word of every piece straight from the XCD's L2 (a wave
+                // instruction covers 256 contiguous bytes of one piece) -- no LDS staging, one barrier less
+                if constexpr (PREC == LAS_PREC_BF16 && MT <= 8) {
+                    constexpr int NP = MT * 4;
+                    const unsigned* src = inbox((s - 1) & (KS_SLOTS - 1), g, 0);
+                    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, G * WPT * 4, 0x00020000);
+                    const int w0 = ev ? eb * WPR + en / 2 : 0x1ffffff0;
+                    unsigned w[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) w[p] = __builtin_amdgcn_raw_buffer_load_b32(rs, (min(p, G - 1) * WPT + w0) * 4, 0, 16);
+                    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const unsigned v = p < G ? w[p] : 0u;
+                        s0[p & 3] += __uint_as_float(v << 16);
+                        s1[p & 3] += __uint_as_float(v & 0xffff0000u);
+                    }
+                    dh_rec[0] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+                    dh_rec[1] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+                }
+            } else {
             // (only the Bl batch rows of each piece that carry data are pulled)
             pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, (Bl * WPR + 3) & ~3, WPT, 0, Pl, WPT);
             __syncthreads();
@@ -692,6 +716,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
                 }
                 dh_rec[0] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
                 dh_rec[1] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+            }
             }
         }
         // pointwise BPTT -> my dgates of this step, into LDS for the product below

@@ -91,7 +91,7 @@ __device__ __forceinline__ bool wait_flags(unsigned* flags, int G, unsigned targ
 // Block-wide wait for `steps` publications of every workgroup of the group; result broadcast through LDS word `flag`.
 __device__ __forceinline__ bool block_wait(unsigned* cnt, int G, unsigned steps, unsigned* abort_word, int* flag, bool local) {
     if (local) {
-        if (threadIdx.x >= LAS_SYNC_THREAD) {
+        if (threadIdx.x >= LAS_SYNC_THREAD && threadIdx.x < NT) {
             const bool ok = wait_flags(cnt + FLAG_OFS, G, steps, abort_word);
             if (threadIdx.x == LAS_SYNC_THREAD) *flag = ok ? 1 : 0;
         }
@@ -182,6 +182,7 @@ struct LstmArgs {
     int sr, concat, T_out, F_out;
     int y_is_hf;
     int xl;                   // XCD-grouped launch: grid = 8 * G * ceil(groups / 8), see lstm_role
+    int pf;                   // forward: a fifth wave prefetches the x-projection rows into the L2 two steps ahead
 };
 
 // Which (direction d, unit slice g, batch slice bs) a workgroup works on.  A GROUP = the G workgroups of one
@@ -239,7 +240,7 @@ __device__ __forceinline__ long y_offset(const LstmArgs& a, int t, int b, int d,
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int PREC, int NB, int KS>     // KS > 0: register-resident operands (bf16), KS k-steps per wave; 0: LDS path
-__global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
+__global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
                                                       float* __restrict__ y, float* __restrict__ hf,
@@ -262,15 +263,58 @@ __global__ __launch_bounds__(NT) void lstm_fwd_kernel(LstmArgs a, const float* _
     int* flag = lensl + NB * 16;
 
     // ---- one-time staging: W_hh rows of my units (zero padded), zero h tile, lens
-    for (int i = threadIdx.x; i < 4 * 16 * ld; i += NT) {
-        const int k = i % ld, n = (i / ld) % 16, gi = i / (ld * 16);
-        float v = 0.f;
-        if (k < H && n < U && j0 + n < H) v = w_hh[((long)d * 4 * H + gi * H + j0 + n) * H + k];
-        Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
+    const bool pfw = threadIdx.x >= NT;                 // the optional fifth wave (a.pf), see below
+    if (!pfw) {
+        for (int i = threadIdx.x; i < 4 * 16 * ld; i += NT) {
+            const int k = i % ld, n = (i / ld) % 16, gi = i / (ld * 16);
+            float v = 0.f;
+            if (k < H && n < U && j0 + n < H) v = w_hh[((long)d * 4 * H + gi * H + j0 + n) * H + k];
+            Wl[i] = PREC == LAS_PREC_BF16 ? (T)f2bf(v) : (T)v;
+        }
+        for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) Hl[i] = (T)0;
+        for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     }
-    for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) Hl[i] = (T)0;
-    for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
     __syncthreads();
+    if (pfw) {
+        // Prefetch wave.  A wave's loads return in issue order, so the HBM-cold read of the x-projection that a
+        // pointwise wave issues at the top of a step (~3 600 cycles) holds back the pull of h it issues 1 700 cycles
+        // later (cycle stamps: the pull took 1 900 cycles, all of it that wait).  This wave touches every 64-byte
+        // segment the workgroup will read two steps from now, so those reads hit the L2; it never waits for its own
+        // loads inside a step and only keeps pace through the workgroup's barriers.
+        const int lane_ = threadIdx.x & 63, segs = NB * 16 * 4;
+        unsigned* cnt_ = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
+        const int gl_ = group_local(a, cnt_, &sync->abort_, flag);
+        if (gl_ < 0) return;
+        constexpr int NQ = (NB * 16 * 4 + 63) / 64;
+        float sink = 0.f, pa[NQ], pb[NQ];               // two sets: a value is consumed two steps after its request,
+#pragma unroll                                          // so this wave never stalls on the way to a barrier
+        for (int q = 0; q < NQ; ++q) pa[q] = pb[q] = 0.f;
+        auto touch = [&](int s, float (&pr)[NQ]) {
+            const int s3 = min(s + 3, a.T - 1), t3 = d == 0 ? s3 : a.T - 1 - s3;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int sg = lane_ + 64 * q, row = sg >> 2, gi = sg & 3;
+                sink += pr[q];
+                pr[q] = (sg < segs && row < Bl) ? xproj[((long)t3 * B + b0 + row) * (ND * 4 * H) + d * 4 * H + gi * H + j0] : 0.f;
+            }
+        };
+        auto step = [&](int s, float (&pr)[NQ]) -> bool {
+            touch(s, pr);
+            if (s > 0) {
+                if (!block_wait(cnt_, a.G, (unsigned)s, &sync->abort_, flag, gl_ == 1)) return false;
+                __syncthreads();                        // pull
+            }
+            __syncthreads();                            // accumulators in LDS
+            __syncthreads();                            // block_signal
+            return true;
+        };
+        for (int s = 0; s < a.T; s += 2) {
+            if (!step(s, pa)) return;
+            if (s + 1 < a.T && !step(s + 1, pb)) return;
+        }
+        if (sink == 1.2345e38f) *status = 0;            // (keeps the loads)
+        return;
+    }
     // register-resident weight fragments of my gate (wave w <-> gate w), read back from the LDS tile once
     bf16x8 wfrag[KS > 0 ? KS : 1];
     if constexpr (KS > 0) {
@@ -860,6 +904,8 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     static const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
     const int groups = ND * a.NS, gpl = (groups + 7) / 8;
     a.xl = (!no_xl && a.G * gpl <= 32) ? 1 : 0;
+    static const bool no_pf = getenv("LAS_LSTM_NO_PF") != nullptr;
+    a.pf = (!no_pf && !(a.dbg & 9)) ? 1 : 0;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
 
@@ -869,7 +915,7 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
                SyncWords* sync, int* status) {
     auto k = lstm_fwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(a.pf ? NT + 64 : NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (typename CT<PREC>::T*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;

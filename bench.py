@@ -121,7 +121,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-b', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=1)
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     cfg = model_cfg(w)

@@ -7,7 +7,9 @@ importlib.import_module('end-to-end-asr-pytorch_amd')
 ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
 dev = 'cuda:0'
 ops.set_precision('bf16')
-T = 300
+import os
+T = int(os.environ.get("T", 300))
+SR = int(os.environ.get("SR", 1))
 for (B, H, ND) in [(24, 320, 2), (12, 320, 2), (12, 320, 1), (24, 160, 2), (12, 160, 2), (12, 64, 2), (12, 32, 1), (12, 16, 1), (48, 320, 2), (24, 512, 2)]:
     I = 64
     x = torch.randn(T, B, I, device=dev, requires_grad=True)
@@ -18,12 +20,12 @@ for (B, H, ND) in [(24, 320, 2), (12, 320, 2), (12, 320, 1), (24, 160, 2), (12, 
     b_hh = torch.zeros(ND * 4 * H, device=dev, requires_grad=True)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     for it in range(2):
-        y = ops.lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, 1, True, status)
+        y = ops.lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, SR, True, status)
         y.backward(torch.ones_like(y))
     ops.join_side_stream(); torch.cuda.synchronize()
     rec = ops.enable_kernel_timing()
     for it in range(3):
-        y = ops.lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, 1, True, status)
+        y = ops.lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, SR, True, status)
         y.backward(torch.ones_like(y))
     ops.join_side_stream(); torch.cuda.synchronize()
     fw = [e0.elapsed_time(e1) for n, e0, e1, *_ in rec if n.startswith('lstm_rec_fwd')]

@@ -222,18 +222,30 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(const float* __restrict_
             if (pt[p] >= g.T) pt[p] -= g.T;
         }
     };
+    // bf16: both operands are k-strided (k = pixel) -> k-major LDS images + transposing reads (gemm_tile.h)
+    auto store = [&](int buf) {
+        if constexpr (PREC == LAS_PREC_BF16) { tile_store_bf16<false>(ra, As2[buf]); tile_store_bf16<false>(rb, Bs2[buf]); }
+        else { s_store<false, T, LD>(ra, As2[buf]); s_store<false, T, LD>(rb, Bs2[buf]); }
+    };
     load(kt0);
-    s_store<false, T, LD>(ra, As2[0]);
-    s_store<false, T, LD>(rb, Bs2[0]);
+    store(0);
     __syncthreads();
     for (long kt = kt0; kt < nk; ++kt) {
         const int cur = (int)(kt - kt0) & 1;
         if (kt + 1 < nk) load(kt + 1);
-        mma_tile<PREC, 4>(As2[cur], Bs2[cur], acc, wm, wn, fr, fq);
-        if (kt + 1 < nk) {
-            s_store<false, T, LD>(ra, As2[cur ^ 1]);
-            s_store<false, T, LD>(rb, Bs2[cur ^ 1]);
-        }
+        if constexpr (PREC == LAS_PREC_BF16) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tile_frag_bf16<false>(As2[cur], wm + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = tile_frag_bf16<false>(Bs2[cur], wn + j * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else mma_tile<PREC, 4>(As2[cur], Bs2[cur], acc, wm, wn, fr, fq);
+        if (kt + 1 < nk) store(cur ^ 1);
         __syncthreads();
     }
 #pragma unroll

@@ -18,50 +18,6 @@ namespace {
 
 using namespace las_tile;
 
-// ---- bf16 operand tiles.  A k-contiguous source keeps the [row][k] image (ds_read_b128 fragments).  A k-strided
-// ("transposed") source used to be transposed in registers and scattered into that image: 8-byte stores whose
-// 32 lanes sit 4 rows = 320 bytes apart, i.e. on 2 of the 32 write banks (16-way conflicts; the weight-gradient
-// shapes, both operands k-strided, ran at 150-200 TFLOP/s).  It now stays k-major in LDS, exactly as it comes from
-// memory ([k][row], 256 contiguous bytes per k row and wave: conflict-free stores), and the MFMA fragments are taken
-// with gfx950's transposing read ds_read_b64_tr_b16 (guide T10): per 16-lane group a 4 (k) x 16 (rows) block, lane i
-// receiving the 4 k values of row i.  The k slot of a lane (fr, fq) is {4 fq .. 4 fq + 3} u {16 + 4 fq .. 16 + 4 fq + 3}
-// (the sum over k does not care, both operands use the same map): one transposing read then covers 8 consecutive k
-// rows per 32-lane half, and with 288-byte rows (128 + 16 elements) those 8 x 32-byte pieces tile the 64 banks exactly.
-// The [row][k] image stores its eight 4-element k chunks in that slot order so that its b128 read needs no change.
-constexpr int LDK = BM + 16;                 // k-major image row stride (elements); 32 * LDK <= BM * (BK + 8)
-typedef short v4s __attribute__((ext_vector_type(4)));
-
-template <bool KCONT>
-__device__ __forceinline__ void tile_store_bf16(const Frag16& reg, bf16_t* __restrict__ tile) {
-    constexpr int LD = BK + Elem<LAS_PREC_BF16>::PAD;
-    const int tid = threadIdx.x;
-    if (KCONT) {
-        const int c = tid & 7, pos = c < 4 ? 8 * c : 8 * (c - 4) + 4;     // logical chunk c -> slot position
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            store4_ct(tile + ((tid >> 3) + 32 * p) * LD + pos, reg.v[4 * p], reg.v[4 * p + 1], reg.v[4 * p + 2], reg.v[4 * p + 3]);
-    } else {
-        const int k = (tid >> 5) * 4, r = (tid & 31) * 4;                  // load p = k offset, 4 consecutive rows each
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            store4_ct(tile + (k + p) * LDK + r, reg.v[4 * p], reg.v[4 * p + 1], reg.v[4 * p + 2], reg.v[4 * p + 3]);
-    }
-}
-
-// MFMA 16x16x32 fragment of rows rb .. rb + 15 (EXEC must be full for the transposing reads: call sites are uniform)
-template <bool KCONT>
-__device__ __forceinline__ bf16x8 tile_frag_bf16(const bf16_t* __restrict__ tile, int rb) {
-    constexpr int LD = BK + Elem<LAS_PREC_BF16>::PAD;
-    const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
-    if (KCONT) return *(const bf16x8*)(tile + (rb + fr) * LD + fq * 8);
-    const int q = fr >> 2, p = fr & 3;                                      // lane 4q+p of its group: block row q, columns 4p..
-    typedef v4s __attribute__((address_space(3))) * lds_v4s;
-    const bf16_t* a0 = tile + (4 * fq + q) * LDK + rb + 4 * p;
-    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)a0);
-    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(a0 + 16 * LDK));
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                   long lda, long sA, const float* __restrict__ B, long ldb, long sB,
@@ -253,7 +209,7 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
         ksplit = (int)((512 + tiles - 1) / tiles);
         const int nk = (K + BK - 1) / BK;
         if (ksplit > nk / 8) ksplit = nk / 8;
-        if (ksplit > 64) ksplit = 64;
+        if (ksplit > 512) ksplit = 512;          // (one-tile outputs with K in the 10^5..10^6: the first conv layer's dW)
         if (ksplit < 1) ksplit = 1;
     }
     // fast path: every operand vector is a whole, 16-byte aligned float4 inside the matrix

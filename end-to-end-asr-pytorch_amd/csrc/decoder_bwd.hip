@@ -9,6 +9,7 @@
 // Sums over the L steps that are plain contractions (dW of every Linear/LSTMCell, d enc, d psi in dot mode)
 // are left to ONE las_gemm each after the loop, on the buffers this call fills.
 #include "las_mma.h"
+#include "graph_cache.h"
 #include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
@@ -483,9 +484,27 @@ int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 extern "C" int64_t las_decoder_loc_acc_floats(int A) { return ((A * LOC_C + A + 1 + 3) / 4) * 4 + LOC_C * LOC_W; }
 extern "C" int las_decoder_att_chunks(int Tp) { return att_chunks(Tp); }
 
+static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                           const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
+                           las_dec_bwd_state* bw_, void* stream);
+
 extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                                const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
                                las_dec_bwd_state* bw_, void* stream) {
+    LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
+    // without dropout no launch argument depends on anything but the call's arguments: one hipGraph (graph_cache.h)
+    if (d->dropout != 0.f || d->L <= 1) return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, stream);
+    static las_graph::Cache cache;
+    las_graph::Key key;
+    key.add(*d); key.add(*p); key.add(*st_); key.add(*bw_); key.add(enc); key.add(psi); key.add(enc_len); key.add(g_htop);
+    return las_graph::run(cache, key, (hipStream_t)stream, [&](hipStream_t s) {
+        return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, (void*)s);
+    });
+}
+
+static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                           const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
+                           las_dec_bwd_state* bw_, void* stream) {
     LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
     const int B = d->B, Tp = d->Tp, E = d->E, A = d->A, C = d->C, NL = d->NL, L = d->L, loc = d->loc, prec = d->prec;
     LAS_CHECK_ARG(B > 0 && Tp > 0 && E > 0 && A > 0 && C > 0 && NL >= 1 && NL <= 4 && L >= 0);

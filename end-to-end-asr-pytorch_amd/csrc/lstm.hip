@@ -36,6 +36,11 @@ constexpr int CNT_STRIDE = 128;     // words per (direction, slice) group, lines
                                     // not share a line with another group's atomics): word 0 arrival counter, words 32-34
                                     // placement rendezvous, words 64-95 per-producer progress words (L2-local mode)
 constexpr int FLAG_OFS = 64;
+// The exchanged h lives in a ring of HX_SLOTS steps per direction (slot = step & 3), not in a [T] history: no workgroup
+// can be more than one step ahead of the slowest reader of its group, and lines that are rewritten every four steps stay
+// resident in the L2 -- a store to a line the L2 does not hold has to wait for its fill before the consumers' reads are
+// served, which cost 0.25 us per step once T*B*H outgrew the memory-side cache (T = 1200: 2.20 vs 1.95 us).
+constexpr int HX_SLOTS = 4;
 struct SyncWords {          // zeroed by hipMemsetAsync before every launch
     unsigned cnt[2 * MAX_SLICES * CNT_STRIDE];   // arrivals per (direction, batch slice)
     unsigned abort_;                // set on spin timeout
@@ -354,7 +359,6 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
 
     for (int s = 0; s < a.T; ++s) {
         const int t = d == 0 ? s : a.T - 1 - s;
-        const int tp = d == 0 ? t - 1 : t + 1;
         // (a) prefetch x-projection of my elements (independent of the recurrence)
         float xp[PE][4];
 #pragma unroll
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
             if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             // every wave needs the whole h tile: one shared pull into LDS (a direct global->register read per wave
             // fetches it four times in fragment-shaped pieces: slower across XCDs, and 2.9 vs 2.06 us inside one)
-            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * a.T + tp) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
+            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * HX_SLOTS + ((s - 1) & (HX_SLOTS - 1))) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
             __syncthreads();
             // (d) gate pre-activations: wave w <-> gate w
             if constexpr (KS > 0) {               // weights from registers, h from LDS
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
             gv[p][0] = mq ? ig : 0.f; gv[p][1] = mq ? fg : 0.f; gv[p][2] = mq ? gg : 0.f; gv[p][3] = mq ? og : 0.f;
             // the unit pair (n, n+1) goes out as one store from the even lane; its partner's h comes over DPP (row_shl:1)
             const float hnext = las_dpp<0x101, 0xf>(0.f, hv[p]);
-            if (ev[p] && !(n & 1)) st_pair_x(hx + (((long)d * a.T + t) * B + b0 + bl) * Hx + j, hv[p], hnext, local);
+            if (ev[p] && !(n & 1)) st_pair_x(hx + (((long)d * HX_SLOTS + (s & (HX_SLOTS - 1))) * B + b0 + bl) * Hx + j, hv[p], hnext, local);
         }
         // (g) publish: only the exchange stores are outstanding here
         block_signal(cnt, local, g, (unsigned)s + 1u);

@@ -62,8 +62,9 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  *   xproj [T][B][ND*4H] (no bias), b_ih/b_hh [ND*4H], w_hh [ND][4H][H], lens [B] (desc. order not required)
  *   y     [T_out][B][F_out] layer output in next-layer layout (see las_lstm_out_shape); zero at t>=len
  *   hf    [T][B][ND*H] hidden history (fp32); may alias y when sr==1
- *   hx    [ND][T][B][Hx] exchange copy in the MFMA operand type (bf16: 2 B/elem, Hx = H rounded up to 8;
- *         f32: 4 B/elem, Hx = H rounded up to 4); when Hx != H the caller zero-fills it once
+ *   hx    exchange workspace in the MFMA operand type (bf16: 2 B/elem, Hx = H rounded up to 8; f32: 4 B/elem, Hx = H
+ *         rounded up to 4): a ring [ND][4][B][Hx] of the last four steps' h (any size >= that, e.g. [ND][T][B][Hx]);
+ *         when Hx != H the caller zero-fills it once
  *   gates [T][B][ND*4H] post-activation gates, cs [T][B][ND*H] cell states (saved for bwd)
  *   sync  las_lstm_sync_bytes() bytes of scratch; status: int32, caller-zeroed, set to LAS_E_TIMEOUT if
  *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).

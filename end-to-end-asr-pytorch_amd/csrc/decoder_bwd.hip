@@ -334,7 +334,9 @@ struct LocPostArgs {
 // with dz_l = de_l * w_e * (1 - s_l^2), du_l = dz_l * (1 - u_l^2), u_l = tanh(W_lp f_l) recomputed.
 // A lane owns one attention dim for POST_TC frames, so its running sums are ~20 registers, >= 8 waves per SIMD hide
 // the HBM latency of the s rows, and no cross-wave reduction is needed (lanes add their sums with coalesced atomics).
-constexpr int POST_TC = 4;
+constexpr int POST_TC = 4;                // frames per lane (8: 907 vs 754 us -- the kernel is VALU-bound: ~55 instructions
+                                          // per frame and step for the u = tanh(W_lp f) recompute, the two 10-term products and the broadcasts)
+constexpr int POST_NAUX = ((LOC_C + 1) * POST_TC + 63) / 64;
 __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
     const int b = blockIdx.y, t0 = blockIdx.x * POST_TC, t1 = min(t0 + POST_TC, a.Tp), len = a.lens[b];
     const int tcv = min(t1, len) - t0;
@@ -351,29 +353,40 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
 #pragma unroll
     for (int c = 0; c < LOC_C; ++c) dwlp_r[c] = 0.f;
     const long step_s = (long)a.B * a.Tp * a.A, step_f = (long)a.B * LOC_C * a.Tp, step_e = (long)a.B * a.Tp;
-    // per (step, frame) side data {de, f[0..9]}: lanes 0..10 of one vector load, broadcast with v_readlane when used
-    const int j = min(lane, LOC_C);                  // 0: de, 1..10: f[j-1]
-    const float* __restrict__ auxp = j == 0 ? a.de + (long)b * a.Tp : a.f + ((long)b * LOC_C + (j - 1)) * a.Tp;
-    const long aux_step = j == 0 ? step_e : step_f;
+    // per-step side data {de, f[0..9]} of the POST_TC frames: ONE vector load per step, lane POST_TC * j + r holding
+    // item j (0: de, 1..10: f[j-1]) of frame r, broadcast with v_readlane when used
+    // (item index li = POST_TC * j + r lives in lane li % 64 of load li / 64)
+    const float* auxp[POST_NAUX];
+    long aux_step[POST_NAUX];
+#pragma unroll
+    for (int q = 0; q < POST_NAUX; ++q) {
+        const int li = lane + 64 * q, j = min(li / POST_TC, LOC_C), ra = li % POST_TC;
+        auxp[q] = (j == 0 ? a.de + (long)b * a.Tp : a.f + ((long)b * LOC_C + (j - 1)) * a.Tp) + min(t0 + ra, t0 + tcv - 1);
+        aux_step[q] = j == 0 ? step_e : step_f;
+    }
     const float* __restrict__ sp0 = a.s + (long)b * a.Tp * a.A + ic;
-    auto load = [&](float (&sv)[POST_TC], float (&aux)[POST_TC], int l) {
+    auto load = [&](float (&sv)[POST_TC], float (&aux)[POST_NAUX], int l) {
 #pragma unroll
         for (int r = 0; r < POST_TC; ++r) {
             const int t = min(t0 + r, t0 + tcv - 1);
             sv[r] = sp0[l * step_s + (long)t * a.A];
-            aux[r] = auxp[l * aux_step + t];
         }
+#pragma unroll
+        for (int q = 0; q < POST_NAUX; ++q) aux[q] = auxp[q][l * aux_step[q]];
     };
-    auto compute = [&](const float (&sv)[POST_TC], const float (&aux)[POST_TC]) {
+    auto item = [&](const float (&aux)[POST_NAUX], int li) {       // li is a compile-time constant at every call site
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[li / 64]), li % 64));
+    };
+    auto compute = [&](const float (&sv)[POST_TC], const float (&aux)[POST_NAUX]) {
 #pragma unroll
         for (int r = 0; r < POST_TC; ++r) {
             if (r >= tcv) break;
-            const float de = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[r]), 0));
+            const float de = item(aux, r);
             dbe += de;
             float fc[LOC_C], u = 0.f;
 #pragma unroll
             for (int c = 0; c < LOC_C; ++c) {
-                fc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[r]), c + 1));
+                fc[c] = item(aux, (c + 1) * POST_TC + r);
                 u += wlp_r[c] * fc[c];
             }
             u = fast_tanh(u);
@@ -386,7 +399,7 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
             for (int c = 0; c < LOC_C; ++c) dwlp_r[c] += du * fc[c];
         }
     };
-    float svA[POST_TC], svB[POST_TC], auxA[POST_TC], auxB[POST_TC];
+    float svA[POST_TC], svB[POST_TC], auxA[POST_NAUX], auxB[POST_NAUX];
     load(svA, auxA, 0);
     for (int l = 0; l < a.L; l += 2) {
         if (l + 1 < a.L) load(svB, auxB, l + 1);

@@ -929,12 +929,12 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     a.y_is_hf = 0;
     { static const char* e = getenv("LAS_DBG_LSTM"); a.dbg = e ? atoi(e) : 0; }
     // XCD-grouped launch when every XCD (32 CUs, one workgroup per CU) can hold the groups dealt to it
-    static const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
+    const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
     const int groups = ND * a.NS, gpl = (groups + 7) / 8;
     a.xl = (!no_xl && a.G * gpl <= 32) ? 1 : 0;
-    static const bool no_nt = getenv("LAS_LSTM_NO_NT") != nullptr;
+    const bool no_nt = getenv("LAS_LSTM_NO_NT") != nullptr;
     a.nt = no_nt ? 0 : 1;
-    static const bool no_pf = getenv("LAS_LSTM_NO_PF") != nullptr;
+    const bool no_pf = getenv("LAS_LSTM_NO_PF") != nullptr;
     a.pf = (!no_pf && !(a.dbg & 9)) ? 1 : 0;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }

@@ -124,6 +124,16 @@ def test_infer_lengths_and_transpose(ops):
     assert ops.count_nonzero(y).cpu().tolist() == [3, 2]
 
 
+@pytest.mark.parametrize('env', ['LAS_LSTM_NO_XL', 'LAS_LSTM_NO_PF', 'LAS_LSTM_NO_NT'])
+def test_lstm_exchange_variants(ops, monkeypatch, env):
+    """The C2 launch geometry (one batch tile, K-split backward) through the paths the default launch does not take on
+    this shape: the cross-XCD sc1 hand-off (no XCD-grouped launch), no prefetch wave, plain stores for the saved
+    activations.  The switches are read at every launch."""
+    monkeypatch.setenv(env, '1')
+    test_lstm_shapes_vs_oracle(ops, 23, 24, 16, 320, 'bf16')
+    test_lstm_shapes_vs_oracle(ops, 17, 12, 8, 64, 'f32')
+
+
 @pytest.mark.parametrize('T,B,Iin,H,prec', [(25, 100, 16, 64, 'f32'), (19, 130, 16, 320, 'f32'), (15, 300, 8, 256, 'f32'),
                                              (21, 24, 16, 512, 'bf16'), (12, 30, 8, 40, 'f32'), (15, 300, 8, 320, 'bf16')])
 def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):

@@ -11,7 +11,6 @@
 //           LSTM cells                         skinny MFMA product, cell epilogue
 // Everything needed by the backward pass is kept in caller-owned buffers (las_dec_state).
 #include "las_mma.h"
-#include "graph_cache.h"
 #include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
@@ -411,17 +410,7 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
 extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                                const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode,
                                unsigned seed, las_dec_state* st_, void* stream) {
-    // teacher-forced, dropout-free loops have no per-call launch argument: replayed as one hipGraph (graph_cache.h)
-    bool fixed = d && p && st_ && y && d->dropout == 0.f && d->L > 1;
-    if (fixed && step_mode)
-        for (int t = 0; t < d->L; ++t) fixed = fixed && step_mode[t] == 1;
-    if (!fixed) return decoder_run(d, p, enc, psi, enc_len, y, Ly, step_mode, seed, st_, stream, false);
-    static las_graph::Cache cache;
-    las_graph::Key key;
-    key.add(*d); key.add(*p); key.add(*st_); key.add(enc); key.add(psi); key.add(enc_len); key.add(y); key.add(Ly);
-    return las_graph::run(cache, key, (hipStream_t)stream, [&](hipStream_t s) {
-        return decoder_run(d, p, enc, psi, enc_len, y, Ly, step_mode, seed, st_, (void*)s, false);
-    });
+    return decoder_run(d, p, enc, psi, enc_len, y, Ly, step_mode, seed, st_, stream, false);
 }
 
 extern "C" int las_decoder_step(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,

@@ -9,7 +9,6 @@
 // Sums over the L steps that are plain contractions (dW of every Linear/LSTMCell, d enc, d psi in dot mode)
 // are left to ONE las_gemm each after the loop, on the buffers this call fills.
 #include "las_mma.h"
-#include "graph_cache.h"
 #include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
@@ -505,14 +504,7 @@ extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, c
                                const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
                                las_dec_bwd_state* bw_, void* stream) {
     LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
-    // without dropout no launch argument depends on anything but the call's arguments: one hipGraph (graph_cache.h)
-    if (d->dropout != 0.f || d->L <= 1) return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, stream);
-    static las_graph::Cache cache;
-    las_graph::Key key;
-    key.add(*d); key.add(*p); key.add(*st_); key.add(*bw_); key.add(enc); key.add(psi); key.add(enc_len); key.add(g_htop);
-    return las_graph::run(cache, key, (hipStream_t)stream, [&](hipStream_t s) {
-        return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, (void*)s);
-    });
+    return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, stream);
 }
 
 static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,

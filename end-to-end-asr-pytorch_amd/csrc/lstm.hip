@@ -181,11 +181,11 @@ __device__ __forceinline__ void mma_direct(f32x4 (&acc)[NB], const bf16_t* __res
 }
 
 struct LstmArgs {
-    int dbg;                  // timing experiments only (LAS_DBG_LSTM): 1 no wait, 2 no pull, 4 no MFMA, 8 no bwd-only stores
     int T, B, H, ND, U, G;
     int NS, Bs;               // batch slices (independent sub-recurrences) and rows per slice
     int sr, concat, T_out, F_out;
     int y_is_hf;
+    int wdirect;              // backward K-split: W_hh fragments straight from global memory (no LDS slab)
     int xl;                   // XCD-grouped launch: grid = 8 * G * ceil(groups / 8), see lstm_role
     int nt;                   // forward: non-temporal stores for the saved activations (C2 step -0.2 ms; the same for the
                               // backward kernel's dgf measured neutral)
@@ -247,7 +247,7 @@ __device__ __forceinline__ long y_offset(const LstmArgs& a, int t, int b, int d,
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int PREC, int NB, int KS>     // KS > 0: register-resident operands (bf16), KS k-steps per wave; 0: LDS path
-__global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
+__global__ __launch_bounds__(KS > 16 ? NT : NT + 64) void lstm_fwd_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
                                                       float* __restrict__ y, float* __restrict__ hf,
@@ -263,8 +263,9 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
     if (role.idle) return;
     const int d = role.d, g = role.g, bs = role.bs, j0 = g * U;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);  // my batch slice: rows [b0, b0+Bl)
-    T* Wl = (T*)smem;                                   // [4][16][ld]
-    T* Hl = Wl + 4 * 16 * ld;                           // [NB*16][ld]
+    constexpr bool WREG = KS > 0;                       // weights in registers, fetched from global memory once
+    T* Wl = (T*)smem;                                   // [4][16][ld]   (LDS path only)
+    T* Hl = Wl + (WREG ? 0 : 4 * 16 * ld);              // [NB*16][ld]
     float* Gl = (float*)(Hl + NB * 16 * ld);            // [4][NB*16][17]
     int* lensl = (int*)(Gl + 4 * NB * 16 * 17);         // [NB*16]
     int* flag = lensl + NB * 16;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
     // ---- one-time staging: W_hh rows of my units (zero padded), zero h tile, lens
     const bool pfw = threadIdx.x >= NT;                 // the optional fifth wave (a.pf), see below
     if (!pfw) {
+        if constexpr (!WREG)
         for (int i = threadIdx.x; i < 4 * 16 * ld; i += NT) {
             const int k = i % ld, n = (i / ld) % 16, gi = i / (ld * 16);
             float v = 0.f;
@@ -322,14 +324,25 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
         if (sink == 1.2345e38f) *status = 0;            // (keeps the loads)
         return;
     }
-    // register-resident weight fragments of my gate (wave w <-> gate w), read back from the LDS tile once
+    // register-resident weight fragments of my gate (wave w <-> gate w): lane (fr, fq) holds k = 32 ks + 8 fq + {0..7}
+    // of W_hh row (gate w, unit j0 + fr), straight from global memory (no LDS slab: at H = 1024 the four gates' rows of
+    // 16 units are 128 KB of bf16, which together with the h tile would not fit the CU's 160 KB)
     bf16x8 wfrag[KS > 0 ? KS : 1];
     if constexpr (KS > 0) {
-        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6, n_ = lane_ & 15;
+        const bool rowok = n_ < U && j0 + n_ < H;
+        const float* wrow = w_hh + ((long)d * 4 * H + wave_ * H + min(j0 + n_, H - 1)) * H;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            wfrag[ks] = (ks * 32 < Kp) ? *(const bf16x8*)((const bf16_t*)Wl + (wave_ * 16 + (lane_ & 15)) * ld + ks * 32 + (lane_ >> 4) * 8)
-                                       : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 32 + (lane_ >> 4) * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wrow[min(c + e, H - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (rowok && c + e < H) ? v[e] : 0.f;
+            const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            wfrag[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
     }
 
     // ---- my pointwise elements: ONE (batch row, unit) per thread and 256-element pass (NB passes): the cell update is
@@ -373,30 +386,36 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             // every wave needs the whole h tile: one shared pull into LDS (a direct global->register read per wave
             // fetches it four times in fragment-shaped pieces: slower across XCDs, and 2.9 vs 2.06 us inside one)
-            if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 2 * NB>(hx + (((long)d * HX_SLOTS + ((s - 1) & (HX_SLOTS - 1))) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
+            // (one pass: all of a thread's loads are in flight before its first LDS write)
+            pull_tile_sc1<T, VEC, (KS > 16 ? 8 : 2) * NB>(hx + (((long)d * HX_SLOTS + ((s - 1) & (HX_SLOTS - 1))) * B + b0) * Hx, Bl, Hx, Hx, 0, Hl, ld);
             __syncthreads();
             // (d) gate pre-activations: wave w <-> gate w
             if constexpr (KS > 0) {               // weights from registers, h from LDS
                 // every fragment is requested before the first MFMA (unconditionally: a k-step beyond Kp re-reads the
                 // last one against a zero weight fragment); issued one by one behind a branch each, the ten
                 // ds_read -> mfma pairs of a wave took 1 460 cycles per step, all of it LDS latency (now 570)
+                // (KS > 16: in chunks of CH k-steps, the h fragments of a whole row would not fit beside the weights)
                 const int lane_ = threadIdx.x & 63;
-                bf16x8 av[KS][NB];
+                constexpr int CH = KS <= 16 ? KS : 8;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int k0 = 0; k0 < KS; k0 += CH) {
+                    bf16x8 av[CH][NB];
 #pragma unroll
-                    for (int bt = 0; bt < NB; ++bt)
-                        av[ks][bt] = *(const bf16x8*)((const bf16_t*)Hl + (bt * 16 + (lane_ & 15)) * ld + min(ks * 32, Kp - 32) + (lane_ >> 4) * 8);
+                    for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                        for (int bt = 0; bt < NB; ++bt)
+                            av[ks][bt] = *(const bf16x8*)((const bf16_t*)Hl + (bt * 16 + (lane_ & 15)) * ld + min((k0 + ks) * 32, Kp - 32) + (lane_ >> 4) * 8);
 #pragma unroll
-                    for (int bt = 0; bt < NB; ++bt)
-                        acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ks][bt], wfrag[ks], acc[bt], 0, 0, 0);
+                    for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt)
+                            acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ks][bt], wfrag[k0 + ks], acc[bt], 0, 0, 0);
+                }
             } else {
-                if (!(a.dbg & 4)) mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
+                mma_rows<PREC, NB>(acc, Hl, ld, Wl + wave * 16 * ld, ld, Kp / KSTEP);
             }
         }
         // (e) accumulators -> LDS  (C/D layout: col = lane&15 = unit, row = (lane>>4)*4 + r = batch)
@@ -427,7 +446,6 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_kernel(LstmArgs a, const flo
         }
         // (g) publish: only the exchange stores are outstanding here
         block_signal(cnt, local, g, (unsigned)s + 1u);
-        if (a.dbg & 8) continue;
 #pragma unroll
         for (int p = 0; p < PE; ++p) {
             if (!ev[p]) continue;
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (!(a.dbg & 1) && !block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+            if (!block_wait(cnt, a.G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             const T* src = dgx + (((long)d * a.T + tn) * B + b0) * K4;
             if constexpr (KS > 0) {
                 mma_direct<NB, KS>(acc, (const bf16_t*)src, Bl, K4, wave * KS * 32, K4 - wave * KS * 32, wfrag);
@@ -559,10 +577,10 @@ __global__ __launch_bounds__(NT) void lstm_bwd_kernel(LstmArgs a, int NC, int K4
             for (int c = 0; c < NC; ++c) {
                 if (c > 0) __syncthreads();               // previous chunk fully consumed
                 // rows have stride K4 in memory; this chunk = real columns [c*KC, c*KC + kreal)
-                if (!(a.dbg & 2)) pull_tile_sc1<T, VEC, 8>(src, Bl, min(KC, K4 - c * KC), K4, c * KC, Dl, ldc);
+                pull_tile_sc1<T, VEC, 8>(src, Bl, min(KC, K4 - c * KC), K4, c * KC, Dl, ldc);
                 __syncthreads();
                 // A = Dl rows (batch) x k ; B = Wl rows (unit) x k, offset to this chunk/wave quarter
-                if (!(a.dbg & 4)) mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);
+                mma_rows<PREC, NB>(acc, Dl + wave * kq * KSTEP, ldc, Wl + c * KC + wave * kq * KSTEP, ldw, kq);
             }
         }
 #pragma unroll
@@ -640,12 +658,14 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
     if (role.idle) return;
     const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
+    const bool wdirect = PREC == LAS_PREC_BF16 && a.wdirect;   // weight fragments fetched from global memory, no LDS slab
     T* Wl = (T*)smem;                                     // [G*16][LDK]  W_hh[my 64 gate rows][every column], k contiguous
-    T* Dl = Wl + (size_t)G * 16 * LDK;                    // [NB*16][LDK] my dgates of this step
+    T* Dl = Wl + (wdirect ? 0 : (size_t)G * 16 * LDK);    // [NB*16][LDK] my dgates of this step
     unsigned* Pl = (unsigned*)(Dl + NB * 16 * LDK);       // [G][WPT] inbox of the previous step
     int* lensl = (int*)(Pl + (size_t)G * WPT);
     int* flag = lensl + NB * 16;
 
+    if (!wdirect)
     for (int i = threadIdx.x; i < G * 16 * KO; i += NT) {
         const int col = i % (G * 16), k = i / (G * 16), gi = k >> 4, n = k & 15;
         float v = 0.f;
@@ -665,8 +685,20 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
         for (int i = 0; i < MT; ++i) {
             const int c = min(wave + 4 * i, G - 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                wfrag[i][ks] = *(const bf16x8*)((const bf16_t*)Wl + (c * 16 + fr) * LDK + ks * 32 + fq * 8);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (!wdirect) { wfrag[i][ks] = *(const bf16x8*)((const bf16_t*)Wl + (c * 16 + fr) * LDK + ks * 32 + fq * 8); continue; }
+                // element e <-> k = 32 ks + 8 fq + e = gate (2 ks + fq/2), unit 8 (fq & 1) + e; output column 16 c + fr
+                // (H = 1024: the [H][64] slab is 147 KB of LDS; one strided read per element instead, once per launch)
+                const int gi = 2 * ks + (fq >> 1), n0 = (fq & 1) * 8, col = c * 16 + fr;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    v[e] = w_hh[((long)d * K4 + gi * H + min(j0 + n0 + e, H - 1)) * H + min(col, H - 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (col < H && j0 + n0 + e < H) ? v[e] : 0.f;
+                const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                wfrag[i][ks] = __builtin_bit_cast(bf16x8, pk);
+            }
         }
     }
 
@@ -709,7 +741,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
         if (s > 0) {
             if (!block_wait(cnt, G, (unsigned)s, &sync->abort_, flag, local)) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
             bool direct_sum = false;
-            if constexpr (PREC == LAS_PREC_BF16 && MT <= 8) direct_sum = local && !(a.dbg & 16);
+            if constexpr (PREC == LAS_PREC_BF16 && MT <= 8) direct_sum = local;
             if (direct_sum) {
                 // L2-local group: each pointwise thread reads its word of every piece straight from the XCD's L2 (a wave
                 // instruction covers 256 contiguous bytes of one piece) -- no LDS staging, one barrier less
@@ -733,7 +765,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
                 }
             } else {
             // (only the Bl batch rows of each piece that carry data are pulled)
-            pull_tile_sc1<unsigned, 4, 4>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, (Bl * WPR + 3) & ~3, WPT, 0, Pl, WPT);
+            pull_tile_sc1<unsigned, 4, (MT > 8 ? 8 : 4)>(inbox((s - 1) & (KS_SLOTS - 1), g, 0), G, (Bl * WPR + 3) & ~3, WPT, 0, Pl, WPT);
             __syncthreads();
             if (ev) {                                     // sum of the G pieces: every LDS read is issued before the first add
                 const unsigned* pw = Pl + eb * WPR + (PREC == LAS_PREC_BF16 ? en / 2 : en);
@@ -872,9 +904,9 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
     }
 }
 
-size_t bwd_ks_lds(int prec, int H, int NB) {
+size_t bwd_ks_lds(int prec, int H, int NB, bool wdirect) {
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, G = (H + 15) / 16;
-    return (size_t)(G * 16 + NB * 16) * (64 + vec) * sz + sizeof(unsigned) * (size_t)G * ks_words_per_tile(prec, NB) +
+    return (size_t)((wdirect ? 0 : G * 16) + NB * 16) * (64 + vec) * sz + sizeof(unsigned) * (size_t)G * ks_words_per_tile(prec, NB) +
            sizeof(int) * (NB * 16 + 4);
 }
 size_t bwd_ks_ring_bytes(int prec, int H, int ND, int NS, int NB) {
@@ -882,10 +914,10 @@ size_t bwd_ks_ring_bytes(int prec, int H, int ND, int NS, int NB) {
     return sizeof(unsigned) * KS_SLOTS * ND * NS * G * G * ks_words_per_tile(prec, NB);
 }
 
-size_t fwd_lds(int prec, int H, int NB) {
+size_t fwd_lds(int prec, int H, int NB, bool wreg) {      // wreg: register-resident weights, no LDS slab
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ks = prec == LAS_PREC_BF16 ? 32 : 16;
     const int Kp = (H + ks - 1) / ks * ks, ld = Kp + vec;
-    return (size_t)(4 * 16 + NB * 16) * ld * sz + sizeof(float) * 4 * NB * 16 * 17 + sizeof(int) * (NB * 16 + 4);
+    return (size_t)((wreg ? 0 : 4 * 16) + NB * 16) * ld * sz + sizeof(float) * 4 * NB * 16 * 17 + sizeof(int) * (NB * 16 + 4);
 }
 int bwd_k4p(int prec, int H) {
     const int q = 4 * (prec == LAS_PREC_BF16 ? 32 : 16);
@@ -909,10 +941,8 @@ int check_common(int T, int B, int H, int ND, int sr) {
 void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int concat) {
     a.T = T; a.B = B; a.H = H; a.ND = ND; a.U = U; a.G = (H + U - 1) / U;
     // batch slices: independent sub-recurrences of <= 16 rows each, as many as the chip has room for
-    static const int rows_env = getenv("LAS_LSTM_ROWS") ? atoi(getenv("LAS_LSTM_ROWS")) : 0;     // (A/B runs only)
     int ns = (B + 11) / 12;
-    if (rows_env >= 1 && rows_env <= 16) ns = (B + rows_env - 1) / rows_env;
-    else if (ns < 8 / ND) {
+    if (ns < 8 / ND) {
         // finer slices (>= 6 rows) as long as every (direction, slice) group still gets an XCD of its own: at C2 four
         // slices of 6 rows on all eight XCDs instead of two of 12 on four (fwd 1.91 -> 1.84, bwd 2.42 -> 2.34 us per
         // step, C2 step -0.4 ms)
@@ -926,8 +956,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     if (sr == 1) { a.T_out = T; a.F_out = ND * H; }
     else if (concat) { a.T_out = T / sr; a.F_out = sr * ND * H; }
     else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
-    a.y_is_hf = 0;
-    { static const char* e = getenv("LAS_DBG_LSTM"); a.dbg = e ? atoi(e) : 0; }
+    a.y_is_hf = 0; a.wdirect = 0;
     // XCD-grouped launch when every XCD (32 CUs, one workgroup per CU) can hold the groups dealt to it
     const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
     const int groups = ND * a.NS, gpl = (groups + 7) / 8;
@@ -935,7 +964,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     const bool no_nt = getenv("LAS_LSTM_NO_NT") != nullptr;
     a.nt = no_nt ? 0 : 1;
     const bool no_pf = getenv("LAS_LSTM_NO_PF") != nullptr;
-    a.pf = (!no_pf && !(a.dbg & 9)) ? 1 : 0;
+    a.pf = no_pf ? 0 : 1;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
 
@@ -945,7 +974,8 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
                SyncWords* sync, int* status) {
     auto k = lstm_fwd_kernel<PREC, NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(a.pf ? NT + 64 : NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+    // (KS > 16: the weight fragments alone are 128 registers per lane -- one wave per SIMD, no prefetch wave)
+    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(a.pf && KS <= 16 ? NT + 64 : NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (typename CT<PREC>::T*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
     return LAS_OK;
@@ -963,6 +993,36 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
 }
 
 
+// Which backward kernel a shape gets, its LDS request and the size of its exchange workspace (`dgx`).
+struct BwdPlan { bool ks, wdirect; int NB, NC, K4p; size_t lds, ws; };
+int bwd_plan(int prec, int T, int B, int H, int ND, const LstmArgs& a, BwdPlan& p) {
+    p.NB = las_pick_nb(a.Bs);
+    if (p.NB == 0 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    // K-split exchange (reduce-scatter of partial dh) whenever it fits: the [H][64] weight slab in LDS, or (bf16) the
+    // weight fragments fetched from global memory into registers (ceil(G / 4) <= 16 tiles per wave: H <= 1024)
+    p.ks = false; p.wdirect = false;
+    if (p.NB <= 2 && !getenv("LAS_LSTM_BWD_GATHER")) {
+        const int mt = (a.G + 3) / 4;
+        if (bwd_ks_lds(prec, H, p.NB, false) <= LDS_CAP && (prec != LAS_PREC_BF16 || mt <= 16)) p.ks = true;
+        else if (prec == LAS_PREC_BF16 && mt <= 16 && bwd_ks_lds(prec, H, p.NB, true) <= LDS_CAP) p.ks = p.wdirect = true;
+    }
+    if (p.ks) {
+        p.lds = bwd_ks_lds(prec, H, p.NB, p.wdirect);
+        p.ws = bwd_ks_ring_bytes(prec, H, ND, a.NS, p.NB);
+        p.NC = 1; p.K4p = 4 * H;
+    } else {
+        const int ks = prec == LAS_PREC_BF16 ? 32 : 16;
+        p.K4p = bwd_k4p(prec, H);
+        p.NC = 1;                                              // chunks must keep whole k-steps per wave and be unpadded if >1
+        while (p.NC <= 8 && (bwd_lds(prec, H, p.NB, p.NC) > LDS_CAP || (p.K4p / p.NC) % (4 * ks) != 0 || (p.NC > 1 && p.K4p != 4 * H))) p.NC *= 2;
+        if (p.NC > 8) return LAS_E_UNSUPPORTED;
+        p.lds = bwd_lds(prec, H, p.NB, p.NC);
+        p.ws = (size_t)ND * T * B * 4 * H * (prec == LAS_PREC_BF16 ? 2 : 4);    // all-gather variant: dgates copy
+    }
+    if (p.lds < MIN_LDS) p.lds = MIN_LDS;
+    return LAS_OK;
+}
+
 }  // namespace
 
 extern "C" void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out) {
@@ -975,11 +1035,10 @@ extern "C" size_t las_lstm_sync_bytes(void) { return sizeof(SyncWords); }
 
 extern "C" size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
+    BwdPlan p;
+    if (check_common(T, B, H, ND, 1)) return 0;
     fill_args(a, T, B, H, ND, 16, 1, 0);
-    const int NB = las_pick_nb(a.Bs);
-    const size_t gather = (size_t)ND * T * B * 4 * H * (prec == LAS_PREC_BF16 ? 2 : 4);     // all-gather variant: dgates copy
-    const size_t ring = NB >= 1 && NB <= 2 ? bwd_ks_ring_bytes(prec, H, ND, a.NS, NB) : 0;   // K-split variant: inbox ring
-    return gather > ring ? gather : ring;
+    return bwd_plan(prec, T, B, H, ND, a, p) == LAS_OK ? p.ws : 0;
 }
 
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
@@ -994,13 +1053,23 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     // use more, smaller unit slices when the chip has room (shorter MFMA chains per step)
     LstmArgs a;
     fill_args(a, T, B, H, ND, U, sr, concat);
-    if (!a.xl && ND * ((H + 7) / 8) <= 256 && H >= 512) {      // (an XCD-grouped launch beats the finer slicing)
-        U = 8;
+    if (!a.xl && ND * ((H + 7) / 8) <= 256 && H >= 512 && H <= 512) {      // (an XCD-grouped launch beats the finer slicing;
+        U = 8;                                                            // beyond 512 two batch slices of 16-unit groups do)
         fill_args(a, T, B, H, ND, U, sr, concat);
     }
     const int NB = las_pick_nb(a.Bs);
     if (NB == 0) return LAS_E_UNSUPPORTED;
-    size_t lds = fwd_lds(prec, H, NB);
+    // bf16: register-resident weight fragments for the common hidden sizes and small batch slices (VGPR budget:
+    // 4 KS for the weights + the h fragments of a chunk); otherwise the weight slab lives in LDS
+    const int ksteps = (H + 31) / 32;
+    int KS = 0;
+    if (prec == LAS_PREC_BF16 && NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT")) {
+        if (ksteps <= 8) KS = 8;
+        else if (ksteps <= 10) KS = 10;
+        else if (ksteps <= 16 && NB == 1) KS = 16;
+    }
+    if (prec == LAS_PREC_BF16 && NB <= 2 && KS == 0 && ksteps <= 32 && fwd_lds(prec, H, NB, false) > LDS_CAP) KS = 32;
+    size_t lds = fwd_lds(prec, H, NB, KS > 0);
     if (lds > LDS_CAP) return LAS_E_UNSUPPORTED;
     a.y_is_hf = (y == hf);
     if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
@@ -1009,12 +1078,10 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
-        // register-resident operands for the common hidden sizes and small batch slices (VGPR budget: KS*4*(1+NB))
-        const int ksteps = ((H + 31) / 32);
-        const bool direct = NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT");
-        if (direct && ksteps <= 8)  { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
-        if (direct && ksteps <= 10) { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
-        if (direct && ksteps <= 16 && NB == 1) { return launch_fwd<LAS_PREC_BF16, 1, 16>(LAS_FWD_ARGS); }
+        if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
+        if (KS == 10) { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
+        if (KS == 16) { return launch_fwd<LAS_PREC_BF16, 1, 16>(LAS_FWD_ARGS); }
+        if (KS == 32) { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 32>(LAS_FWD_ARGS))); }
         LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_, 0>(LAS_FWD_ARGS)));
     } else {
         LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_F32, NB_, 0>(LAS_FWD_ARGS)));
@@ -1032,34 +1099,28 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     LstmArgs a;
     fill_args(a, T, B, H, ND, 16, sr, concat);
-    const int NB = las_pick_nb(a.Bs);
-    if (NB == 0) return LAS_E_UNSUPPORTED;
-    const int ks = prec == LAS_PREC_BF16 ? 32 : 16;
-    const int K4p = bwd_k4p(prec, H);
-    int NC = 1;                                                  // chunks must keep whole k-steps per wave and be unpadded if >1
-    while (NC <= 8 && (bwd_lds(prec, H, NB, NC) > LDS_CAP || (K4p / NC) % (4 * ks) != 0 || (NC > 1 && K4p != 4 * H))) NC *= 2;
-    if (NC > 8 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
-    size_t lds = bwd_lds(prec, H, NB, NC);
-    if (lds < MIN_LDS) lds = MIN_LDS;
+    BwdPlan p;
+    rc = bwd_plan(prec, T, B, H, ND, a, p);
+    if (rc) return rc;
+    const int NB = p.NB, NC = p.NC, K4p = p.K4p;
+    a.wdirect = p.wdirect ? 1 : 0;
+    const size_t lds = p.lds;
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
-    // K-split exchange (reduce-scatter of partial dh) whenever its weight slab fits in LDS
-    if (NB <= 2 && bwd_ks_lds(prec, H, NB) <= LDS_CAP && !getenv("LAS_LSTM_BWD_GATHER")) {
-        size_t l2 = bwd_ks_lds(prec, H, NB);
-        if (l2 < MIN_LDS) l2 = MIN_LDS;
+    if (p.ks) {
 #define LAS_KS_GO(P_, N_, M_)                                                                                          \
     {                                                                                                                 \
         auto k = lstm_bwd_ks_kernel<P_, N_, M_>;                                                                      \
-        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));            \
-        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), l2, st, a, dy, gates, cs, w_hh, lens, (unsigned*)dgx, dgf, \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT), lds, st, a, dy, gates, cs, w_hh, lens, (unsigned*)dgx, dgf, \
                            (SyncWords*)sync, status);                                                                 \
         LAS_LAUNCH_OK();                                                                                              \
         return LAS_OK;                                                                                                \
     }
         const int mt = (a.G + 3) / 4;
         if (prec == LAS_PREC_BF16) {
-            if (NB == 1) { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 1, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 1, 8) else if (mt <= 16) LAS_KS_GO(LAS_PREC_BF16, 1, 16) }
-            else { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 2, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 2, 8) else if (mt <= 16) LAS_KS_GO(LAS_PREC_BF16, 2, 16) }
+            if (NB == 1) { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 1, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 1, 8) else LAS_KS_GO(LAS_PREC_BF16, 1, 16) }
+            else { if (mt <= 5) LAS_KS_GO(LAS_PREC_BF16, 2, 5) else if (mt <= 8) LAS_KS_GO(LAS_PREC_BF16, 2, 8) else LAS_KS_GO(LAS_PREC_BF16, 2, 16) }
         } else { if (NB == 1) LAS_KS_GO(LAS_PREC_F32, 1, 1) else LAS_KS_GO(LAS_PREC_F32, 2, 1) }
 #undef LAS_KS_GO
     }

@@ -55,18 +55,22 @@ def infer_lengths(x):
 
 
 # ----------------------------------------------------------------------------- encoder
-def lstm_dir(x, lens, w_ih, w_hh, b_ih, b_hh, reverse):
-    """One direction of a packed LSTM, explicit time loop.  x (B,T,I) -> (B,T,H), zeros at t>=len."""
+def lstm_dir(x, lens, w_ih, w_hh, b_ih, b_hh, reverse, bf16_operands=False):
+    """One direction of a packed LSTM, explicit time loop.  x (B,T,I) -> (B,T,H), zeros at t>=len.
+    bf16_operands (forward checks only): the operands of both matrix products are rounded to bf16 (RNE), sums and
+    state stay fp32 -- the arithmetic of the product's bf16 mode, so that mode can be checked to 1e-3 instead of 5e-2."""
     B, T, _ = x.shape
     H = w_hh.shape[1]
-    xp = x @ w_ih.t() + (b_ih + b_hh)
+    r = _rb if bf16_operands else (lambda t_: t_)
+    w_hh = r(w_hh)
+    xp = r(x) @ r(w_ih).t() + (b_ih + b_hh)
     lens_t = torch.as_tensor(lens)
     h = x.new_zeros(B, H)
     c = x.new_zeros(B, H)
     outs = [None] * T
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        g = xp[:, t] + h @ w_hh.t()
+        g = xp[:, t] + r(h) @ w_hh.t()
         i, f, gg, o = g.chunk(4, dim=-1)
         c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
         h_new = torch.sigmoid(o) * torch.tanh(c_new)
@@ -98,9 +102,11 @@ def lstm_dir_fast(x, lens, w_ih, w_hh, b_ih, b_hh, reverse):
     return y
 
 
-def rnn_layer(x, lens, W, prefix, sr, style, bidir, fast=False):
+def rnn_layer(x, lens, W, prefix, sr, style, bidir, fast=False, bf16_operands=False):
     """asr.py:476-501.  Returns (y, out_lens)."""
     f = lstm_dir_fast if fast else lstm_dir
+    if bf16_operands:
+        f = lambda *a: lstm_dir(*a, bf16_operands=True)
     T = max(lens)                                  # pad_packed_sequence trims to the longest
     x = x[:, :T]
     p = prefix + '.layer.'

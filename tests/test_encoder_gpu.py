@@ -135,11 +135,16 @@ def test_lstm_exchange_variants(ops, monkeypatch, env):
 
 
 @pytest.mark.parametrize('T,B,Iin,H,prec', [(25, 100, 16, 64, 'f32'), (19, 130, 16, 320, 'f32'), (15, 300, 8, 256, 'f32'),
-                                             (21, 24, 16, 512, 'bf16'), (12, 30, 8, 40, 'f32'), (15, 300, 8, 320, 'bf16')])
+                                             (21, 24, 16, 512, 'bf16'), (12, 30, 8, 40, 'f32'), (15, 300, 8, 320, 'bf16'),
+                                             (13, 24, 32, 1024, 'bf16'), (7, 24, 4096, 1024, 'bf16'), (9, 40, 16, 1024, 'bf16'),
+                                             (11, 12, 16, 768, 'bf16')])
 def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):
     """The launch geometries beyond the C2 shape: many batch slices (B=100), two batch tiles per slice (B=130 at H=320),
     four (B=300 at H=256: LDS-resident weights forward, all-gather backward), H=512 (8-unit workgroups forward, 32 pieces in the
-    K-split backward), H not a multiple of 16.  Against the oracle (torch packed LSTM), ragged lengths; f32 mode where its
+    K-split backward), H not a multiple of 16; H = 1024 (BASELINE configs[4], SURVEY 8d C5: 64 workgroups per direction and batch
+    slice, the weight fragments of both kernels fetched from global memory into registers, cross-XCD hand-off; B = 24 as two
+    slices of 12, B = 40 as two batch tiles per slice, the 4096-wide concat input of C5's layers 1-2) and H = 768 (zero-padded
+    k-steps of the same kernels).  Against the oracle (torch packed LSTM), ragged lengths; f32 mode where its
     LDS-resident f32 weight slab fits (H < ~500 at one batch tile, H <= 256 at four), bf16 mode (8e-2 / 5e-2) otherwise."""
     from oracle import las_ref as R
     rng = np.random.RandomState(T * 1000 + B)
@@ -180,3 +185,32 @@ def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):
     close(w_ih.grad / scale, g_ih / scale, tol)
     close(w_hh.grad / scale, g_hh / scale, tol)
     close(b_ih.grad / scale, g_bi / scale, tol)
+
+
+@pytest.mark.parametrize('T,B,Iin,H,sr', [(23, 24, 64, 1024, 2), (31, 24, 160, 320, 2), (19, 24, 32, 512, 1)])
+def test_lstm_bf16_forward_tight(ops, T, B, Iin, H, sr):
+    """bf16 mode against the oracle run with the SAME operand rounding (bf16 RNE operands, fp32 sums and state): 2e-3
+    instead of the 5e-2 that separates bf16 from the reference's pure-fp32 arithmetic -- a wrong low-order term would
+    show.  C5 (H=1024) and C2 (H=320) layer geometries with concat down-sampling, and H=512."""
+    from oracle import las_ref as R
+    rng = np.random.RandomState(H + T)
+    lens = sorted(rng.randint(max(1, T // 2), T + 1, size=B).tolist(), reverse=True); lens[0] = T
+    x = np.zeros((B, T, Iin), np.float32)
+    for b, l in enumerate(lens):
+        x[b, :l] = rng.randn(l, Iin)
+    W = {}
+    for sfx in ['', '_reverse']:
+        W['L.layer.weight_ih_l0' + sfx] = torch.tensor((rng.randn(4 * H, Iin) / np.sqrt(Iin)).astype(np.float32))
+        W['L.layer.weight_hh_l0' + sfx] = torch.tensor((rng.randn(4 * H, H) / np.sqrt(H)).astype(np.float32))
+        W['L.layer.bias_ih_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32))
+        W['L.layer.bias_hh_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32))
+    yr, _ = R.rnn_layer(torch.tensor(x), lens, W, 'L', sr, 'concat', True, bf16_operands=True)
+    dd = {k[len('L.layer.'):]: v.numpy() for k, v in W.items()}
+    w_ih, w_hh, b_ih, b_hh = [T_(v) for v in cat_lstm_weights(dd, '', True)]
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.set_precision('bf16')
+    y = ops.transpose01(ops.lstm_layer(ops.transpose01(T_(x)), torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                       w_ih, w_hh, b_ih, b_hh, sr, True, status))
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    close(y, yr.numpy(), dict(atol=2e-3, rtol=2e-3))

@@ -1,12 +1,16 @@
 #!/usr/bin/env python
-"""Headline benchmark: real mel-frames/s of the full LAS train step (H2D-free: batches pre-staged in HBM ->
-forward -> joint loss -> backward -> gradient all-reduce -> clip -> optimiser) on synthetic 80-dim fbank batches.
+"""Headline benchmark: real mel-frames/s of the full LAS+CTC train step (forward -> joint CTC + CE loss -> backward ->
+gradient all-reduce -> clip -> optimiser) on synthetic 80-dim fbank batches.
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workloads: c2 (default; BASELINE.json configs[1]: LibriSpeech-100h char-level LAS, attention-only,
-bf16), c3 (= c2 + joint_ctc 0.5), c4 (V=5000, L_max=60), c1 (timit_example.yaml shapes, fp32 MFMA).
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing) and `cpu_baseline`
+Workloads: c3 (default; BASELINE.json configs[2], the config the metric "LAS+CTC" is quoted on:
+LibriSpeech-100h hybrid CTC+attention, ctc_weight 0.5, bf16, 1 GPU), c2 (configs[1]: the same model attention-only), c4
+(configs[3]: V=5000, L_max=60), c5 (configs[4]: 6x1024 pBLSTM, V=5000), c1 (configs[0]: timit_example.yaml shapes, fp32
+MFMA), libri_vgg / libri_vgg_max (the reference's shipped config/libri_example.yaml with its VGG front-end).
+`value` is measured with the batches resident in HBM when the timed region starts; the same loop fed from pinned host
+memory (the H2D copy of SURVEY.md §8d inside the timed region) is reported beside it as config.value_incl_h2d.
+Prints ONE JSON line (rank 0) with `roofline` (the dominant single kernel, live HIP-event timing) and `cpu_baseline`
 (the CPU oracle timed on this host on a bounded sample of the same workload)."""
 import argparse
 import importlib
@@ -33,12 +37,16 @@ WORKLOADS = {
     'c4': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
                enc=('320_320_320_320_320', '2_2_1_1_1'), att=('loc', 300), dec=320,
                name='LibriSpeech-360h subword (V=5000) LAS+CTC, bf16'),
-    # the reference's shipped config/libri_example.yaml, verbatim: VGG front-end + 5x320 BiLSTM (no pyramid), loc-attn, CTC 0.5
+    # SURVEY.md 8d C5 = BASELINE configs[4]: 6-layer pBLSTM x 1024 (2_2_1_1_1_1 concat), loc-attn A=300, dec 1x1024, V=5000
     'c5': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+               enc=('1024_1024_1024_1024_1024_1024', '2_2_1_1_1_1'), att=('loc', 300), dec=1024,
+               name='LibriSpeech-960h subword (V=5000), 6-layer pBLSTM x 1024 + loc-attn, joint CTC-attn 0.5, bf16'),
+    # the reference's shipped config/libri_example.yaml, verbatim: VGG front-end + 5x320 BiLSTM (no pyramid), loc-attn, CTC 0.5
+    'libri_vgg': dict(D=80, V=5000, B=24, T_max=1200, L_max=60, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
                enc=('320_320_320_320_320', '1_1_1_1_1'), enc_type='VGGBiRNN', style='drop', att=('loc', 300), dec=320,
                name='config/libri_example.yaml: VGGBiRNN (VGG front-end + 5x320 BiLSTM), loc-attn, CTC 0.5, V=5000, bf16'),
     # stress shape, not a headline: the same config at its `max_timestep: 3000` / `max_label_len: 400` limits
-    'c6': dict(D=80, V=5000, B=24, T_max=3000, L_max=400, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
+    'libri_vgg_max': dict(D=80, V=5000, B=24, T_max=3000, L_max=400, prec='bf16', opt=('Adadelta', 1.0), ctc=0.5,
                enc=('320_320_320_320_320', '1_1_1_1_1'), enc_type='VGGBiRNN', style='drop', att=('loc', 300), dec=320,
                name='config/libri_example.yaml at max_timestep 3000 / max_label_len 400 (stress shape)'),
 }
@@ -63,7 +71,7 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
     from oracle import las_ref as R
     synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
     tr = time_reduction(w)
-    x, y, lens = synth.make_batch(0, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr)
+    x, y, lens = synth.make_batch(0, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr, ctc=w['ctc'] > 0)
     x, y, lens = x[:sample_B], y[:sample_B], lens[:sample_B]
     torch.manual_seed(0)
     try:
@@ -89,24 +97,23 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
                        f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
 
 
-PMC_KEYS = {'lstm_rec_fwd': 'lstm_fwd_kernel', 'lstm_rec_bwd': 'lstm_bwd_', 'gemm': 'gemm_kernel<0, true, true',
-            'vgg_fwd': 'conv_fwd_kernel<0, 2, 0>', 'vgg_bwd': 'conv_wgrad_kernel'}
-
-
 def attach_pmc_traffic(roof, workload):
-    """`traffic` = HBM bytes per launch of the group's dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    The profiler cannot run inside the bench, so the figure comes from profiles/r01_pmc_traffic_<workload>.json."""
-    path = os.path.join(ROOT, 'profiles', f'r01_pmc_traffic_{workload}.json')
+    """`traffic` = HBM bytes per launch of a single-kernel row from this round's rocprofv3 --pmc passes of THIS command
+    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
+    summarised by tools/pmc_summary.py into profiles/r02_pmc_traffic_<workload>.json.  The profiler cannot run inside
+    the bench, so a row whose kernel is not in that file keeps traffic = null."""
+    path = os.path.join(ROOT, 'profiles', f'r02_pmc_traffic_{workload}.json')
     if not os.path.exists(path):
         return
     pmc = json.load(open(path))
     for row in [roof] + roof.get('breakdown', []):
-        key = next((v for k, v in PMC_KEYS.items() if row.get('kernel', '').startswith(k)), None)
-        hit = next((v for n, v in pmc.items() if key and key in n), None)
-        if hit:
-            row['traffic'] = hit['hbm_MB_per_launch_corrected'] * 1e6
-            row['traffic_unit'] = 'B/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)'
+        if not row.get('single_kernel'):
+            continue
+        hits = [v for n, v in pmc.items() if n.split('<')[0] == row['kernel']]
+        if hits:
+            n = sum(h['launches'] for h in hits)
+            row['traffic'] = sum(h['hbm_MB_per_launch_corrected'] * h['launches'] for h in hits) / n * 1e6
+            row['traffic_unit'] = 'B/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes, ' + os.path.basename(path) + ')'
 
 
 def note(msg):
@@ -118,7 +125,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-b', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=1)
@@ -149,18 +156,22 @@ def main():
     t.load_data()
     t.set_model()
     dev = t.device
-    # pre-stage distinct batches in HBM (per-step seed = 1234 + global batch index; each rank its own shard)
+    # pre-stage distinct batches (per-step seed = 1234 + global batch index; each rank its own shard): in HBM for the
+    # timed region behind `value`, and in pinned host memory for the H2D-inclusive loop
     n_stage = min(8, a.steps + a.warmup)
-    staged = []
+    staged, pinned = [], []
     for i in range(n_stage):
-        x, y, lens = synth.make_batch(i * world + rank, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr)
+        x, y, lens = synth.make_batch(i * world + rank, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr, ctc=w['ctc'] > 0)
         staged.append((x.to(dev), y.to(dev), sum(lens), (lens, int((y != 0).sum(-1).max()))))
+        pinned.append((x.pin_memory(), y.pin_memory()))
     t.asr_opt.zero_grad()
 
-    def run(k0, k, known_lengths=False):
+    def run(k0, k, known_lengths=False, from_host=False):
         frames = 0
         for i in range(k0, k0 + k):
             x, y, f, hl = staged[i % n_stage]
+            if from_host:                      # the reference's per-step H2D (solver.py:132-133), from pinned memory
+                x, y = (v.to(dev, non_blocking=True) for v in pinned[i % n_stage])
             t.train_step(x, y, 1.0, host_lens=hl if known_lengths else None)
             frames += f
         return frames
@@ -187,6 +198,17 @@ def main():
         dt, frames = float(tmax), float(fsum)
     assert int(t.asr_model.status.item()) == 0, 'persistent LSTM hand-off timed out'
     skipped = bool(t.asr_opt.norm3[2].item())
+    # the same loop with the batch coming from pinned host memory inside the timed region
+    barrier()
+    t1 = time.perf_counter()
+    frames_h = run(a.warmup, a.steps, from_host=True)
+    barrier()
+    dt_h = time.perf_counter() - t1
+    stat_h = torch.tensor([dt_h, float(frames_h)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(stat_h[0:1], op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(stat_h[1:2], op=torch.distributed.ReduceOp.SUM)
+    dt_h, frames_h = float(stat_h[0]), float(stat_h[1])
 
     note(f'{dt * 1e3 / a.steps:.1f} ms/step; kernel timing pass')
     # ---- roofline of the dominant kernel: live HIP-event timing of its launches over 3 more steps
@@ -207,13 +229,17 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'mel-frames/sec per train step (LAS+CTC, 80-dim fbank)', 'value': frames / dt, 'unit': 'mel-frames/s',
+            'metric': 'mel-frames/sec per train step (LAS+CTC, 80-dim fbank)' if w['ctc'] > 0 else
+                      'mel-frames/sec per train step (LAS attention-only, 80-dim fbank)',
+            'value': frames / dt, 'unit': 'mel-frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt * 1e3 / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if w['prec'] == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': f"{a.workload}: {w['name']}", 'per_gpu_batch': w['B'], 'global_batch': w['B'] * world,
                        'T_max': w['T_max'], 'L_max': w['L_max'], 'D': w['D'], 'V': w['V'], 'optimizer': w['opt'][0],
-                       'params': int(t.asr_model.n_params), 'parallelism': f'dp{world}', 'nan_skipped_last_step': skipped},
+                       'joint_ctc': w['ctc'], 'params': int(t.asr_model.n_params), 'parallelism': f'dp{world}',
+                       'nan_skipped_last_step': skipped, 'value_incl_h2d': frames_h / dt_h,
+                       'ms_per_step_incl_h2d': dt_h * 1e3 / a.steps},
             'roofline': roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -1041,6 +1041,14 @@ extern "C" size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND) {
     return bwd_plan(prec, T, B, H, ND, a, p) == LAS_OK ? p.ws : 0;
 }
 
+extern "C" int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND) {
+    LstmArgs a;
+    BwdPlan p;
+    if (check_common(T, B, H, ND, 1)) return 0;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    return bwd_plan(prec, T, B, H, ND, a, p) == LAS_OK && p.ks ? 1 : 0;
+}
+
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                                 const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
                                 float* hf, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {

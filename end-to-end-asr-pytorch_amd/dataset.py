@@ -36,25 +36,40 @@ def _pad_y(ys, max_len=0):
 
 
 class _Buckets:
-    def __init__(self, shuffle):
+    """Pre-bucketed batches.  Data parallel (world > 1): every bucket is dealt round-robin over the ranks by utterance
+    (dist.shard_bucket's rule: rank r takes utterances r, r + world, ... of the length-sorted bucket, which balances the
+    frame counts and keeps each shard sorted); all ranks walk the buckets in the same order (the shuffle draws from
+    Python's `random`, which main.py seeds identically on every rank).  `last_global_B` is the size of the whole bucket
+    the last yielded shard came from: shards of one bucket can differ in size (half-batch rule, trailing bucket), and
+    the Trainer weights its gradient by B_local / B_global."""
+
+    def __init__(self, shuffle, rank=0, world=1):
         self.shuffle = shuffle
         self.items = []
+        self.rank, self.world = int(rank), max(1, int(world))
+        self.last_global_B = None
 
     def __len__(self):
         return len(self.items)
+
+    def bucket_size(self, i):
+        return len(self.items[i][0])
 
     def __iter__(self):
         order = list(range(len(self.items)))
         if self.shuffle:
             random.shuffle(order)
         for i in order:
-            x, y = self.get(i)
+            B = self.bucket_size(i)
+            idx = list(range(self.rank, B, self.world)) if self.world > 1 else None
+            x, y = self.get(i, idx)
+            self.last_global_B = B
             yield torch.from_numpy(x).unsqueeze(0), torch.from_numpy(y).unsqueeze(0)
 
 
 class TimitBuckets(_Buckets):
-    def __init__(self, path, sets, bucket_size, max_timestep=0, max_label_len=0, shuffle=False):
-        super().__init__(shuffle)
+    def __init__(self, path, sets, bucket_size, max_timestep=0, max_label_len=0, shuffle=False, rank=0, world=1):
+        super().__init__(shuffle, rank, world)
         x, y = [], []
         for s in sets:
             with open(os.path.join(path, s + '_x.pkl'), 'rb') as fp:
@@ -69,13 +84,14 @@ class TimitBuckets(_Buckets):
             L = min(max_label_len, max(len(y[i]) for i in idx)) if max_label_len else 0
             self.items.append((_pad_x([x[i] for i in idx], T), _pad_y([y[i] for i in idx], L)))
 
-    def get(self, i):
-        return self.items[i]
+    def get(self, i, idx=None):
+        x, y = self.items[i]
+        return (x, y) if idx is None else (x[idx], y[idx])
 
 
 class LibriBuckets(_Buckets):
-    def __init__(self, path, sets, bucket_size, max_timestep=0, max_label_len=0, drop=False, shuffle=False):
-        super().__init__(shuffle)
+    def __init__(self, path, sets, bucket_size, max_timestep=0, max_label_len=0, drop=False, shuffle=False, rank=0, world=1):
+        super().__init__(shuffle, rank, world)
         import pandas as pd
         self.root = path
         tab = pd.concat([pd.read_csv(os.path.join(path, s + '.csv')) for s in sets], ignore_index=True)
@@ -99,8 +115,13 @@ class LibriBuckets(_Buckets):
         if cur:
             self.items.append(cur)
 
-    def get(self, i):
-        items = self.items[i]
+    def bucket_size(self, i):
+        return len(self.items[i])
+
+    def get(self, i, idx=None):
+        items = self.items[i] if idx is None else [self.items[i][k] for k in idx]
+        if not items:                                       # a bucket smaller than the world: nothing for this rank
+            return np.zeros((0, 1, 1), np.float32), np.zeros((0, 2), np.int64)
         xs = [np.load(os.path.join(self.root, f)).astype(np.float32) for f, _, _ in items]
         return _pad_x(xs), _pad_y([l for _, _, l in items])
 
@@ -120,9 +141,10 @@ def LoadDataset(split, text_only, data_path, batch_size, max_timestep, max_label
         raise NotImplementedError(split)
     name = dataset.upper()
     if name == 'TIMIT':
-        return TimitBuckets(data_path, sets, bs, max_timestep, max_label_len, shuffle)
+        return TimitBuckets(data_path, sets, bs, max_timestep, max_label_len, shuffle, kwargs.get('rank', 0), kwargs.get('world', 1))
     if name == 'LIBRISPEECH':
-        return LibriBuckets(data_path, sets, bs, max_timestep, max_label_len, drop, shuffle)
+        return LibriBuckets(data_path, sets, bs, max_timestep, max_label_len, drop, shuffle, kwargs.get('rank', 0),
+                            kwargs.get('world', 1))
     if name == 'SYNTHETIC':
         s = kwargs.get('synthetic', {})
         n = s.get('n_batches', 8) if split == 'train' else s.get('n_dev_batches', 1)

@@ -207,7 +207,7 @@ class DecoderFn(torch.autograd.Function):
             setattr(bw, k, v.data_ptr())
         st = S['_keep'][1]
         g_htop = g_htop.contiguous()
-        with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (2 * A + E) * (2 if loc else 1), 'byte'):
+        with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (A + E), 'byte'):      # enc + saved s (loc) / psi (dot)
             check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
                                      ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
         # ---- contractions over the L steps: one GEMM each; the weight gradients are off the dependency chain and go

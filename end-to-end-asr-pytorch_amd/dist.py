@@ -1,5 +1,6 @@
-"""One process per GPU; utterance batch sharded by rank; ONE sum all-reduce of the flat fp32 gradient vector over
-RCCL/xGMI per step (new functionality: the reference is single-device).
+"""One process per GPU; utterance batch sharded by rank; a sum all-reduce of the flat fp32 gradient vector over
+RCCL/xGMI per step, in per-layer buckets launched DURING backward as soon as a bucket's last weight gradient is
+enqueued (new functionality: the reference is single-device).
 
 Both losses are per-utterance normalised then batch-meaned (solver.py:152-154, CTC 'mean'), so with equal shard
 sizes mean-over-ranks of the local gradient equals the global-batch gradient: all-reduce(sum) then scale by
@@ -53,3 +54,58 @@ def shard_bucket(x, y, lens, rank, world):
     """Deal a length-sorted global bucket round-robin over ranks (balances sum T), keep descending order."""
     idx = list(range(rank, x.shape[0], world))
     return x[idx], y[idx], [lens[i] for i in idx]
+
+
+# ----------------------------------------------------------------------------- bucketed all-reduce under backward
+# The flat gradient vector is laid out in forward order: [VGG | encoder layer 0 (LSTM, proj) | layer 1 | ... | attention |
+# decoder | embed | char_trans | ctc_layer].  Backward produces it from the END: when encoder layer l's BPTT has been
+# enqueued, every gradient at or beyond that layer's first parameter is final (its weight-gradient GEMMs sit on the side
+# stream, the decoder's returned gradients were accumulated on the main stream).  At that moment the range
+# [layer l start, previous boundary) goes out as one all-reduce on RCCL's own stream, which is made to wait for exactly
+# those two streams' tails, and runs under the BPTT of the layers below (the encoder's layer 0, the longest, lands last).
+# xGMI rings are per-link bound, so buckets are whole layers (1.7 - 4.6 MB at C2, 34 - 134 MB at C5), not small chunks.
+_COMM = {'stream': None}
+
+
+def _comm_stream():
+    if _COMM['stream'] is None:
+        _COMM['stream'] = torch.cuda.Stream()
+    return _COMM['stream']
+
+
+def backward_with_overlap(loss, model, bucket_elems=64 * 1024 * 1024):
+    """loss.backward() + the gradient exchange.  Single process: just backward and the side-stream join."""
+    from . import ops
+    flat = model.flat_grads
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not flat.is_cuda:
+        loss.backward()
+        ops.join_side_stream()
+        allreduce_grads(flat)
+        return
+    st = {'hi': flat.numel(), 'works': []}
+    comm = _comm_stream()
+    base = flat.data_ptr()
+
+    def ready(lo):
+        """everything at flat offsets >= lo has been enqueued (main or side stream)"""
+        lo = max(0, min(int(lo), st['hi']))
+        if lo >= st['hi']:
+            return
+        comm.wait_stream(torch.cuda.current_stream())
+        if ops._SIDE['stream'] is not None:
+            comm.wait_stream(ops._SIDE['stream'])
+        with torch.cuda.stream(comm):                         # the collective's stream waits for comm's tail only
+            for off in range(lo, st['hi'], bucket_elems):
+                st['works'].append(dist.all_reduce(flat[off:min(off + bucket_elems, st['hi'])], op=dist.ReduceOp.SUM,
+                                                   async_op=True))
+        st['hi'] = lo
+
+    ops._GRAD_READY = lambda first_grad: ready((first_grad.data_ptr() - base) // 4)
+    try:
+        loss.backward()
+    finally:
+        ops._GRAD_READY = None
+    ops.join_side_stream()
+    ready(0)
+    for w in st['works']:
+        w.wait()                                              # the current stream waits for the collective

@@ -22,10 +22,13 @@ def disable_kernel_timing():
 
 
 class _Timed:
-    """Brackets a C-ABI call with HIP events on the stream the kernels are launched on (torch's current stream)."""
+    """Brackets a C-ABI call with HIP events on the stream the kernels are launched on (torch's current stream).
+    name: the rocprofv3 kernel name when the call is ONE kernel launch (single=True), a descriptive group name otherwise;
+    work: algorithmic flops / bytes of the call (SURVEY.md 8d formulas); dep_steps: dependent timesteps inside the launch
+    (persistent recurrences: the figure that matters there is us per dependent step)."""
 
-    def __init__(self, name, work, unit):
-        self.args = (name, work, unit)
+    def __init__(self, name, work, unit, single=False, dep_steps=0):
+        self.args = (name, work, unit, single, dep_steps)
 
     def __enter__(self):
         if _TIMING is not None:
@@ -37,34 +40,39 @@ class _Timed:
     def __exit__(self, *exc):
         if _TIMING is not None:
             self.e1.record()
-            _TIMING.append((self.args[0], self.e0, self.e1, self.args[1], self.args[2]))
+            _TIMING.append((self.args[0], self.e0, self.e1, self.args[1], self.args[2], self.args[3], self.args[4]))
         return False
 
 
 def kernel_timing_summary(records):
-    """Group the timed launches; the dominant group (largest total time) becomes the `roofline` object."""
+    """Group the timed launches.  The `roofline` object is the dominant SINGLE kernel (largest total time among the
+    groups that are one kernel launch per call, named as rocprofv3 names it); every group is in `breakdown`."""
     torch.cuda.synchronize()
     groups = {}
-    for name, e0, e1, work, unit in records:
-        g = groups.setdefault(name, dict(ms=0.0, n=0, work=0.0, unit=unit))
+    for name, e0, e1, work, unit, single, dep in records:
+        g = groups.setdefault(name, dict(ms=0.0, n=0, work=0.0, unit=unit, single=single, dep=0))
         g['ms'] += e0.elapsed_time(e1)
         g['n'] += 1
         g['work'] += work
+        g['dep'] += dep
     rows = []
     for name, g in groups.items():
         sec = g['ms'] * 1e-3
         if g['unit'] == 'flop':
             peak = PEAK['mfma_f32'] if _prec else PEAK['mfma_bf16']
             ach = g['work'] / sec / 1e12 if sec > 0 else 0.0
-            rows.append(dict(kernel=name, bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak,
-                             launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms']))
+            row = dict(kernel=name, bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak)
         else:
             ach = g['work'] / sec / 1e9 if sec > 0 else 0.0
-            rows.append(dict(kernel=name, bound='hbm', achieved=ach, peak=PEAK['hbm'], unit='GB/s', frac=ach / PEAK['hbm'],
-                             launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms']))
+            row = dict(kernel=name, bound='hbm', achieved=ach, peak=PEAK['hbm'], unit='GB/s', frac=ach / PEAK['hbm'])
+        row.update(launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms'], single_kernel=bool(g['single']),
+                   algorithmic_work_per_launch=g['work'] / g['n'], traffic=None)
+        if g['dep']:
+            row['us_per_dependent_step'] = g['ms'] * 1e3 / g['dep']
+        rows.append(row)
     rows.sort(key=lambda r: -r['total_ms'])
-    top = dict(rows[0]) if rows else {}
-    top['traffic'] = None
+    singles = [r for r in rows if r['single_kernel']]
+    top = dict((singles or rows)[0]) if rows else {}
     top['breakdown'] = rows
     return top
 
@@ -74,6 +82,8 @@ def kernel_timing_summary(records):
 # occupy only ND*ceil(H/16)*slices CUs: run the wgrads on a second HIP stream, accumulating directly into the
 # flat gradient buffer (param.grad views), and join before the optimiser.
 _SIDE = {'enabled': True, 'stream': None, 'dirty': False}
+_GRAD_READY = None      # dist.backward_with_overlap: called with an encoder layer's first gradient view once that layer's
+                        # (and therefore every later parameter's) gradients have all been enqueued
 
 
 def set_wgrad_overlap(flag):
@@ -139,9 +149,10 @@ def _ctc_fwd(logits, label, enc_len, tgt_len, blank):
     ws = _ws(nbytes, dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     la = torch.empty(B, T, 2 * L + 1, dtype=torch.float32, device=dev)
-    check(L_.las_ctc_loss_fwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
-                              I(blank), ptr(nll), ptr(la), ptr(ws), Z(ws.numel()), cur_stream()),
-          'las_ctc_loss_fwd')
+    with _Timed('ctc_loss_fwd (row pass + alpha scan)', 4.0 * B * T * (V + 2 * L + 1), 'byte'):
+        check(L_.las_ctc_loss_fwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
+                                  I(blank), ptr(nll), ptr(la), ptr(ws), Z(ws.numel()), cur_stream()),
+              'las_ctc_loss_fwd')
     return nll, la, (logits, label, enc_len, tgt_len, nll, la, ws, blank)
 
 
@@ -152,9 +163,10 @@ def _ctc_bwd(saved, gscale):
     L = label.shape[1]
     grad = torch.empty_like(logits)
     gs = gscale.contiguous().float()
-    check(L_.las_ctc_loss_bwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
-                              I(blank), ptr(nll), ptr(la), ptr(gs), ptr(grad), ptr(ws), Z(ws.numel()),
-                              cur_stream()), 'las_ctc_loss_bwd')
+    with _Timed('ctc_loss_bwd (beta scan + gradient row pass)', 4.0 * B * T * (2 * V + 2 * L + 1), 'byte'):
+        check(L_.las_ctc_loss_bwd(ptr(logits), ptr(label), ptr(enc_len), ptr(tgt_len), I(B), I(T), I(V), I(L),
+                                  I(blank), ptr(nll), ptr(la), ptr(gs), ptr(grad), ptr(ws), Z(ws.numel()),
+                                  cur_stream()), 'las_ctc_loss_bwd')
     return grad
 
 
@@ -216,7 +228,7 @@ def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=Non
         if batch > 1:
             sC = M * N
     ldc = ldc if ldc is not None else C.stride(-2)
-    with _Timed('gemm (MFMA, fused epilogue)', 2.0 * M * N * K * batch, 'flop'):
+    with _Timed('gemm_kernel (all layouts / epilogues)', 2.0 * M * N * K * batch, 'flop'):
         check(L_.las_gemm(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha), P(A.data_ptr()), LL(lda),
                           LL(sA), P(B.data_ptr()), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc), LL(sC),
                           P(bias.data_ptr()) if bias is not None else None, I(act), I(batch), cur_stream()), 'las_gemm')
@@ -348,7 +360,7 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-    with _Timed('lstm_rec_fwd (persistent BiLSTM recurrence)', 2.0 * ND * T * B * H4 * H, 'flop'):
+    with _Timed('lstm_fwd_kernel', 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
                                   I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
                                   ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
@@ -368,7 +380,8 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     dgx = torch.empty(L_.las_lstm_bwd_ws_bytes(I(prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-    with _Timed('lstm_rec_bwd (persistent BiLSTM BPTT)', 2.0 * ND * T * B * H4 * H, 'flop'):
+    ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
+    with _Timed('lstm_bwd_ks_kernel' if ksplit else 'lstm_bwd_kernel', 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
                                   I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
               'las_lstm_rec_bwd')
@@ -438,6 +451,8 @@ class _LstmLeavesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         gx, gw_ih, gw_hh, gb = _lstm_bwd(ctx.saved, gy, ctx.needs_input_grad[0], ctx.cat_grads)
+        if _GRAD_READY is not None and ctx.cat_grads is not None:
+            _GRAD_READY(ctx.cat_grads[0])
         ND = ctx.saved[3].shape[0]
         n_leaves = len(ctx.shapes)
         ctx.saved = None

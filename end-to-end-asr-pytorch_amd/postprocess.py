@@ -92,3 +92,16 @@ def cal_cer(pred_ids, label, mapper, get_sentence=False):
         return pred, lab
     eds = [float(edit_distance(p.split(' '), l.split(' '))) / len(l.split(' ')) for p, l in zip(pred, lab)]
     return sum(eds) / len(eds)
+
+
+def draw_att(att_list, pred_ids):
+    """3-channel attention images of the first head, one per utterance, cut at the hypothesis' <eos>
+    (reference postprocess.py:149-155).  att_list[0]: (B, L, T') tensor / array; pred_ids: integer array [B, L]."""
+    import numpy as np
+    att0 = att_list[0]
+    att0 = att0.detach().cpu().numpy() if hasattr(att0, 'detach') else np.asarray(att0)
+    maps = []
+    for att, hyp in zip(att0, pred_ids):
+        n = len(trim_eos(hyp))
+        maps.append(np.stack([att, att, att], axis=0)[:, :n, :])
+    return maps

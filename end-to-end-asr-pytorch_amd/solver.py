@@ -17,7 +17,7 @@ from . import ops, dist as ldist
 from .asr import Seq2Seq
 from .dataset import LoadDataset
 from .optim import FlatOptimizer
-from .postprocess import Mapper, cal_acc, cal_cer
+from .postprocess import Mapper, cal_acc, cal_cer, draw_att
 
 VAL_STEP = 30            # reference solver.py:18-20
 TRAIN_WER_STEP = 250
@@ -48,10 +48,13 @@ class ScalarLog:
 
     def add_text(self, name, txt, step):
         self.f.write(json.dumps({'step': int(step), 'name': name, 'text': str(txt)}) + '\n')
+        self.f.flush()
         if self.tb:
             self.tb.add_text(name, txt, step)
 
     def add_image(self, name, img, step):
+        self.f.write(json.dumps({'step': int(step), 'name': name, 'image_shape': [int(v) for v in getattr(img, 'shape', ())]}) + '\n')
+        self.f.flush()
         if self.tb:
             self.tb.add_image(name, img, step)
 
@@ -110,8 +113,9 @@ class Trainer(Solver):
     def load_data(self):
         self.verbose('Loading data from ' + str(self.config['solver'].get('data_path')))
         kw = dict(self.config['solver'])
-        kw.update(rank=self.rank, world=self.world)
-        self.train_set = LoadDataset('train', text_only=False, use_gpu=self.paras.gpu, **kw)
+        # data parallel: every training bucket is dealt over the ranks by utterance (dist.shard_bucket); the dev set is
+        # small and evaluated whole on every rank (rank 0 logs and saves)
+        self.train_set = LoadDataset('train', text_only=False, use_gpu=self.paras.gpu, rank=self.rank, world=self.world, **kw)
         self.dev_set = LoadDataset('dev', text_only=False, use_gpu=self.paras.gpu, **kw)
         for self.sample_x, _ in self.train_set:          # one example sizes the model (solver.py:79)
             break
@@ -136,12 +140,19 @@ class Trainer(Solver):
         ldist.broadcast_params(self.asr_model.flat_params)
 
     # ------------------------------------------------------------------------------------------------ one step
-    def train_step(self, x, y, tf_rate, host_lens=None):
+    def train_step(self, x, y, tf_rate, host_lens=None, shard_weight=1.0):
         """The body of the reference's training loop, solver.py:127-182.  x (B,T,D) / y (B,L+2) on the device.
         Returns device scalars (loss, att, ctc) and the predictions; nothing here waits on the GPU except the
         single small read-back of lengths.  `host_lens=(state_len, ans_len)` skips that read-back when the caller
         already knows the lengths on the host (bench.py's kernel-timing pass uses it so that no event bracket
-        contains a host bubble; the timed region of the benchmark does NOT)."""
+        contains a host bubble; the timed region of the benchmark does NOT).  `shard_weight` = B_local * world /
+        B_global (1 for equal shards): both losses are batch means, so the global-batch gradient is the B_local-weighted
+        mean of the ranks' gradients."""
+        if x.shape[0] == 0:                                       # a bucket smaller than the world: nothing on this rank,
+            ldist.allreduce_grads(self.asr_model.flat_grads)      # but it still joins the exchange and the (global) update
+            self.asr_opt.step(zero_grad=True)
+            z = torch.zeros((), device=self.device)
+            return z, z, z, None, 0
         lens = ops.infer_lengths(x)                               # solver.py:134, on the device
         ntok = ops.count_nonzero(y)                               # solver.py:136,159
         if host_lens is None:
@@ -152,9 +163,7 @@ class Trainer(Solver):
         ctc_pred, enc_len, att_pred, _ = self.asr_model(x, ans_len, tf_rate=tf_rate, teacher=y, state_len=state_len)
         loss, att_loss, ctc_loss = ops.joint_loss(att_pred, ctc_pred, y, ntok, self.asr_model.last_enc_len_dev, ans_len,
                                                   self.ctc_weight)
-        loss.backward()                                           # solver.py:177
-        ops.join_side_stream()                                    # weight-gradient GEMMs ran on the side stream
-        ldist.allreduce_grads(self.asr_model.flat_grads)
+        ldist.backward_with_overlap(loss if shard_weight == 1.0 else loss * shard_weight, self.asr_model)   # solver.py:177
         self.asr_opt.step(zero_grad=True)                         # clip 5, NaN guard, update (solver.py:178-182)
         return loss, att_loss, ctc_loss, att_pred, ans_len
 
@@ -169,7 +178,9 @@ class Trainer(Solver):
                 assert len(y.shape) == 3, 'Bucketing should cause label have to shape 1xBxT'
                 x = x.squeeze(0).to(device=self.device, dtype=torch.float32, non_blocking=True)
                 y = y.squeeze(0).to(device=self.device, dtype=torch.long, non_blocking=True)
-                loss, att_loss, ctc_loss, att_pred, ans_len = self.train_step(x, y, tf_rate)
+                gB = getattr(self.train_set, 'last_global_B', None) or int(x.shape[0]) * self.world
+                loss, att_loss, ctc_loss, att_pred, ans_len = self.train_step(x, y, tf_rate,
+                                                                              shard_weight=int(x.shape[0]) * self.world / gB)
                 self._log_train(loss, att_loss, ctc_loss, att_pred, y, ans_len)
                 if self.step % self.valid_step == 0:
                     self.valid()
@@ -181,7 +192,8 @@ class Trainer(Solver):
     # ------------------------------------------------------------------------------------------------ logging
     def _log_train(self, loss, att_loss, ctc_loss, att_pred, y, ans_len):
         """Scalars of solver.py:185-190, read back one step late (pinned, non-blocking)."""
-        vals = [loss.detach().view(1), att_loss.view(1), ctc_loss.view(1), self.asr_opt.norm3]
+        vals = [loss.detach().view(1), att_loss.view(1), ctc_loss.view(1), self.asr_opt.norm3,
+                self.asr_model.status.float()]             # persistent-kernel hand-off status rides along: no extra sync
         if att_pred is not None:
             pred = ops.argmax_rows(att_pred)
             vals.append(ops.token_acc(pred, y).view(1))
@@ -205,6 +217,7 @@ class Trainer(Solver):
         ev.synchronize()
         v = buf.tolist()
         self.last_scalars = dict(step=step, loss=v[0], att=v[1], ctc=v[2], grad_norm=v[3], skipped=bool(v[5]))
+        self._check_status(int(v[6]), 'train step %d' % step)
         if v[5]:
             self.verbose('Error : grad norm is NaN @ step ' + str(step))
         if self.log is None:
@@ -217,9 +230,19 @@ class Trainer(Solver):
         d['train_full'] = v[0]
         self.log.add_scalars('loss', d, step)
         if has_att:
-            self.log.add_scalars('acc', {'train': v[6]}, step)
+            self.log.add_scalars('acc', {'train': v[7]}, step)
         if cer is not None:
             self.log.add_scalars('error rate', {'train': cer}, step)
+
+    def _check_status(self, code=None, where=''):
+        """A persistent LSTM kernel whose hand-off spin ran out (LAS_E_TIMEOUT: its workgroups were not all co-resident,
+        e.g. two processes on one GPU) leaves its outputs partly unwritten: never train on, validate with or checkpoint
+        that.  `code` None reads the flag from the device (one small sync: validation / decoding only)."""
+        if code is None:
+            code = int(self.asr_model.status.item())
+        if code != 0:
+            raise ops._lib.LasError('persistent LSTM kernel reported status %d (%s) during %s: results are invalid'
+                                    % (code, 'hand-off spin timeout' if code == -4 else 'error', where))
 
     def write_log(self, val_name, val_dict):
         if self.log is None:
@@ -233,10 +256,22 @@ class Trainer(Solver):
 
     # ------------------------------------------------------------------------------------------------ validation
     def valid(self):
-        """Greedy-decoding validation, reference solver.py:211-291."""
+        """Greedy-decoding validation, reference solver.py:211-291: eval mode for its duration
+        (solver.py:211,287: no Speller dropout), no-teacher argmax feedback for ans_len + VAL_STEP steps, dev losses,
+        error rate / accuracy, attention maps + hypotheses + references of the LAST bucket (solver.py:266-276), best
+        checkpoint + best_hyp.txt."""
+        was_training = self.asr_model.training
+        self.asr_model.eval()
+        try:
+            self._valid_body()
+        finally:
+            self.asr_model.train(was_training)
+
+    def _valid_body(self):
         val_ctc = val_att = val_acc = val_cer = 0.0
         val_len = 0
         all_pred, all_true = [], []
+        pred = label = att_maps = None
         with torch.no_grad():
             for x, y in self.dev_set:
                 if len(x.shape) == 4:
@@ -266,12 +301,19 @@ class Trainer(Solver):
                 if ctc_pred is not None:
                     val_ctc += float(c_l) * B
                 val_len += B
+        self._check_status(None, 'validation')
         val_loss = (1 - self.ctc_weight) * val_att + self.ctc_weight * val_ctc
         loss_log = {k: v / val_len for k, v in zip(['dev_full', 'dev_ctc', 'dev_att'], [val_loss, val_ctc, val_att]) if v > 0.0}
         self.write_log('loss', loss_log)
         if self.ctc_weight < 1:
             self.write_log('error rate', {'dev': val_cer / val_len})
             self.write_log('acc', {'dev': val_acc / val_len})
+            # attention maps / hypotheses / references of the last bucket (solver.py:266-276)
+            val_hyp, val_txt = cal_cer(pred, label, mapper=self.mapper, get_sentence=True)
+            for idx, attmap in enumerate(draw_att(att_maps, pred)):
+                self.write_log('att_' + str(idx), attmap)
+                self.write_log('hyp_' + str(idx), val_hyp[idx])
+                self.write_log('txt_' + str(idx), val_txt[idx])
             if val_cer / val_len < self.best_val_ed and self.rank == 0:
                 self.best_val_ed = val_cer / val_len
                 self.verbose('Best val er       : {:.4f}       @ step {}'.format(self.best_val_ed, self.step))
@@ -304,7 +346,10 @@ class Tester(Solver):
         self.best_val_ed = -1.0                      # never overwrite the checkpoint from the Tester's dev check
 
     def write_log(self, name, d):
-        self.verbose('{}: {}'.format(name, {k: round(float(v), 4) for k, v in d.items()}))
+        if isinstance(d, dict):                      # the Tester has no TensorBoard: scalars and texts go to stdout,
+            self.verbose('{}: {}'.format(name, {k: round(float(v), 4) for k, v in d.items()}))
+        elif isinstance(d, str):                     # attention images are dropped (the reference's Tester.valid logs none)
+            self.verbose('{}: {}'.format(name, d))
 
     def load_data(self):
         self.verbose('Loading testing data ' + str(self.config['solver']['test_set']) + ' from ' +
@@ -342,6 +387,8 @@ class Tester(Solver):
         self.valid()
 
     valid = Trainer.valid                             # greedy attention decoding on the dev set (solver.py:389-441)
+    _valid_body = Trainer._valid_body
+    _check_status = Trainer._check_status
 
     def save_checkpoint(self, path):                  # the Tester never saves
         pass
@@ -380,6 +427,7 @@ class Tester(Solver):
         x = x[:, :max(state_len)].contiguous() if not self.asr_model.vgg else x
         max_decode_step = int(math.ceil(state_len[0] * self.decode_step_ratio))
         hyps = self.asr_model.beam_decode(x, max_decode_step, state_len, self.decode_beam_size)
+        self._check_status(None, 'beam decoding')
         self.write_hyp(hyps, y)
         return hyps
 

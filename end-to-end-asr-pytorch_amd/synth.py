@@ -12,9 +12,11 @@ def total_downsample(sample_rate):
     return r
 
 
-def make_batch(step, B, T_max, D, V, L_max, time_reduction=1, seed=1234, min_frac=0.6, l_frac=0.5, full_length=False):
+def make_batch(step, B, T_max, D, V, L_max, time_reduction=1, seed=1234, min_frac=0.6, l_frac=0.5, full_length=False, ctc=True):
     """Per-step seed s = seed + step; T_b ~ U{ceil(min_frac*T_max)..T_max} with one forced to T_max; labels
-    n_b ~ U{ceil(l_frac*L_max)..L_max}, tokens ~ U{2..V-1}; CTC-feasible (n_b + 1 + repeats <= T'_b)."""
+    n_b ~ U{ceil(l_frac*L_max)..L_max}, tokens ~ U{2..V-1}.  SURVEY.md 8d: with a CTC loss in the step (`ctc`) a label is
+    cut to the longest prefix that is CTC-feasible, n_b + 1 (<eos>) + repeats <= T'_b; an attention-only step keeps every
+    label as drawn."""
     rng = np.random.RandomState(seed + step)
     lens = [T_max] + [T_max if full_length else int(rng.randint(math.ceil(min_frac * T_max), T_max + 1)) for _ in range(B - 1)]
     lens = sorted(lens, reverse=True)
@@ -25,9 +27,12 @@ def make_batch(step, B, T_max, D, V, L_max, time_reduction=1, seed=1234, min_fra
     ns = [int(rng.randint(max(1, math.ceil(l_frac * L_max)), L_max + 1)) for _ in range(B)]
     y = np.zeros((B, max(ns) + 2), np.int64)
     for b, n in enumerate(ns):
-        tp = lens[b] // time_reduction
-        n = max(1, min(n, (tp - 1) // 2))                # 2n+1 <= T' covers every repeat
-        y[b, 1:n + 1] = rng.randint(2, V, size=n)
+        tok = rng.randint(2, V, size=n)
+        if ctc:
+            tp = lens[b] // time_reduction
+            need = np.arange(1, n + 1) + 1 + np.concatenate([[0], np.cumsum(tok[1:] == tok[:-1])])   # prefix k: k + 1 + repeats
+            n = max(1, int((need <= tp).sum()))
+        y[b, 1:n + 1] = tok[:n]
         y[b, n + 1] = 1
     return torch.from_numpy(x), torch.from_numpy(y), lens
 

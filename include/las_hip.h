@@ -74,6 +74,7 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
 void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
 size_t las_lstm_sync_bytes(void);
 size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size of the `dgx` exchange workspace of rec_bwd */
+int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* 1: rec_bwd runs lstm_bwd_ks_kernel (reduce-scatter of partial dh), 0: lstm_bwd_kernel */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
                      void* hx, float* gates, float* cs, void* sync, int* status, void* stream);

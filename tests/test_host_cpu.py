@@ -89,9 +89,15 @@ def test_synthetic_batch_contract():
         assert (x[b, l:] == 0).all() and (x[b, :l].abs().sum(-1) != 0).all()
         n = int((y[b] != 0).sum()) - 1
         assert y[b, 0] == 0 and y[b, n + 1] == 1 and (y[b, n + 2:] == 0).all() and (y[b, 1:n + 1] >= 2).all()
-        assert 2 * (n + 1) + 1 <= l // 4 + 2          # CTC-feasible with the <eos>
+        rep = int((y[b, 2:n + 2] == y[b, 1:n + 1]).sum())
+        assert (n + 1) + rep <= l // 4                 # CTC-feasible: tokens + <eos> + repeats <= T' 
     x2, y2, _ = synth.make_batch(3, 6, 50, 7, 11, 9, time_reduction=4)
     assert torch.equal(x, x2) and torch.equal(y, y2)
+    # attention-only workloads keep every label as drawn (no clamp), CTC ones only cut what is infeasible
+    _, y3, _ = synth.make_batch(3, 6, 50, 7, 11, 30, time_reduction=4, ctc=False)
+    _, y4, _ = synth.make_batch(3, 6, 50, 7, 11, 30, time_reduction=4, ctc=True)
+    n3, n4 = (y3 != 0).sum(-1) - 1, (y4 != 0).sum(-1) - 1
+    assert int(n3.min()) >= 15 and int(n4.max()) <= 50 // 4 - 1 and (n4 <= n3).all()
     assert synth.total_downsample('2_2_1_1_1') == 4
 
 
@@ -139,3 +145,102 @@ def test_main_cli_flags():
     a = main.parse(['--config', 'config/x.yaml', '--seed', '3', '--cpu', '--no-msg'])
     assert a.config == 'config/x.yaml' and a.seed == 3 and a.gpu is False and a.verbose is False
     assert a.logdir == 'log/' and a.ckpdir == 'result/' and a.njobs == 1 and not a.test and not a.rnnlm
+
+
+def _write_libri_dir(d, root):
+    """Rebuild the csv + .npy directory the reference's LoadDataset saw when tools/gen_golden.py::g8_libri ran."""
+    D = int(d['D'])
+    for split in ['train', 'dev', 'test']:
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        with open(os.path.join(root, split + '.csv'), 'w') as f:
+            f.write('file_path,length,label\n')
+            for row in d[f'{split}.csv']:
+                f.write(str(row) + '\n')
+                fp, n, _ = str(row).split(',')
+                # content: a deterministic function of the path (the golden stores per-frame sums of two buckets only)
+                np.save(os.path.join(root, fp), np.full((int(n), D), 1.0 + (hash_path(fp) % 7), np.float32))
+
+
+def hash_path(fp):
+    return sum(ord(c) for c in fp)
+
+
+SOLVER_LIBRI = dict(batch_size=4, max_timestep=1200, max_label_len=400, use_gpu=False, n_jobs=0, dataset='librispeech',
+                    train_set=['train'], dev_set=['dev'], test_set=['test'], dev_batch_size=4, decode_beam_size=1, dev_step=10)
+
+
+def test_libri_buckets_match_reference_loader(tmp_path):
+    """N4 pinned: bucket membership AND order of LibriBuckets against the reference's LoadDataset (tests/golden/g8_*, made
+    by tools/gen_golden.py from /root/reference/src/dataset.py:57-155): half-batch rule by length (> 800) and by label
+    length (> 150), drop filters for train/dev but not test, ties in length, trailing partial bucket, single-utterance test
+    buckets when decode_beam_size > 1, zero-padded labels."""
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g8_libri_buckets.npz'))
+    root = str(tmp_path)
+    _write_libri_dir(d, root)
+    for split in ['train', 'dev', 'test']:
+        ds = dataset.LoadDataset(split, text_only=False, data_path=root, **SOLVER_LIBRI)
+        assert len(ds) == int(d[f'{split}.n_buckets']), split
+        for i in range(len(ds)):
+            assert [f for f, _, _ in ds.items[i]] == [str(v) for v in d[f'{split}.bucket{i}.files']], (split, i)
+            x, y = ds.get(i)
+            assert list(x.shape) == list(d[f'{split}.bucket{i}.xshape'])
+            np.testing.assert_array_equal(y, d[f'{split}.bucket{i}.y'])
+            lens = [(x[b].sum(-1) != 0).sum() for b in range(x.shape[0])]
+            assert lens == sorted(lens, reverse=True)
+    ds = dataset.LoadDataset('test', text_only=False, data_path=root, **dict(SOLVER_LIBRI, decode_beam_size=5))
+    assert [b[0][0] for b in ds.items] == [str(v) for v in d['test_beam.files']] and all(len(b) == 1 for b in ds.items)
+    # the train split saw the half-batch rule (by length and by label length) and both drop filters
+    sizes = [len(b) for b in dataset.LoadDataset('train', text_only=False, data_path=root, **SOLVER_LIBRI).items]
+    assert sizes == [2, 2, 4, 2, 2, 4, 3]
+
+
+@pytest.mark.parametrize('kind', ['timit', 'libri'])
+def test_buckets_are_sharded_over_ranks(tmp_path, kind):
+    """Data parallel on real data: at world = 2 (and 3: unequal shards) the ranks' shards of every bucket are
+    disjoint, cover it, stay sorted by length, and all ranks walk the buckets in the same (shuffled) order."""
+    import random
+    root = str(tmp_path)
+    if kind == 'libri':
+        d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g8_libri_buckets.npz'))
+        _write_libri_dir(d, root)
+        mk = lambda r, w: dataset.LoadDataset('train', text_only=False, data_path=root, rank=r, world=w, **SOLVER_LIBRI)
+    else:
+        rng = np.random.RandomState(0)
+        xs = [rng.randn(n, 4).astype(np.float32) for n in rng.randint(5, 40, size=11)]
+        ys = [[0] + rng.randint(2, 9, size=rng.randint(1, 5)).tolist() + [1] for _ in xs]
+        pickle.dump(xs, open(tmp_path / 'train_x.pkl', 'wb'))
+        pickle.dump(ys, open(tmp_path / 'train_y.pkl', 'wb'))
+        mk = lambda r, w: dataset.LoadDataset('train', text_only=False, data_path=root, rank=r, world=w,
+                                              **dict(SOLVER_LIBRI, dataset='timit', max_timestep=0, max_label_len=0))
+    for world in (2, 3):
+        random.seed(5)
+        full = [(x[0], y[0]) for x, y in mk(0, 1)]
+        shards = []
+        for r in range(world):
+            random.seed(5)                                   # main.py seeds `random` identically on every rank
+            ds = mk(r, world)
+            got = []
+            for x, y in ds:
+                got.append((x[0], y[0], ds.last_global_B))
+            shards.append(got)
+        assert all(len(s) == len(full) for s in shards)
+        for i, (fx, fy) in enumerate(full):
+            B = fx.shape[0]
+            assert all(s[i][2] == B for s in shards)
+            assert sum(s[i][0].shape[0] for s in shards) == B
+            for r in range(world):
+                sx, sy, _ = shards[r][i]
+                idx = list(range(r, B, world))
+                assert sx.shape[0] == len(idx)
+                for k, b in enumerate(idx):
+                    n = int((fx[b].abs().sum(-1) != 0).sum())
+                    assert torch.equal(sx[k, :n], fx[b, :n]) and (sx[k, n:] == 0).all()
+                    L = int((fy[b] != 0).sum()) + 1
+                    assert torch.equal(sy[k, :L], fy[b, :L])
+
+
+def test_draw_att_shapes():
+    att = [np.arange(2 * 5 * 3, dtype=np.float32).reshape(2, 5, 3)]
+    maps = post.draw_att(att, np.array([[4, 1, 2, 2, 2], [3, 3, 3, 3, 3]]))
+    assert maps[0].shape == (3, 2, 3) and maps[1].shape == (3, 5, 3)          # cut at <eos> (postprocess.py:149-155)
+    assert np.array_equal(maps[0][1], att[0][0, :2])

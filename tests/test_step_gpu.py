@@ -59,7 +59,7 @@ def test_step_vs_reference(las, name, prec):
     if 'ctc_pred' in d.files:
         np.testing.assert_allclose(ctc_pred.detach().cpu().numpy(), d['ctc_pred'], **tol)
     lt = 2e-5 if f32 else 2e-2
-    assert abs(float(loss) - float(d['loss'])) <= lt * max(1.0, abs(float(d['loss'])))
+    assert abs(float(loss.detach()) - float(d['loss'])) <= lt * max(1.0, abs(float(d['loss'])))
     assert abs(float(att_loss) - float(d['att_loss'])) <= lt * max(1.0, abs(float(d['att_loss'])))
     assert abs(float(ctc_loss) - float(d['ctc_loss'])) <= lt * max(1.0, abs(float(d['ctc_loss'])))
     gmax = max(np.abs(d[k]).max() for k in d.files if k.startswith('grad.'))

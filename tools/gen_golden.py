@@ -58,11 +58,13 @@ def _install_shims():
         def add_scalars(self, name, d, step):
             SummaryWriter.trace.append((int(step), name, {k: float(v) for k, v in d.items()}))
 
-        def add_image(self, *a, **k):
-            pass
+        texts, images = [], []
 
-        def add_text(self, *a, **k):
-            pass
+        def add_image(self, name, img, step):
+            SummaryWriter.images.append((int(step), name, np.asarray(img).copy()))
+
+        def add_text(self, name, txt, step):
+            SummaryWriter.texts.append((int(step), name, str(txt)))
     tbx.SummaryWriter = SummaryWriter
     sys.modules['tensorboardX'] = tbx
 
@@ -455,6 +457,175 @@ def g6_beam(asr, out):
             np.savez(os.path.join(out, f'g6_beam_{name}_b{beam}.npz'), **d)
 
 
+
+# ----------------------------------------------------------------------------- G7 validation (next-row N2)
+def _timit_dir(rng, V, D, sizes, Tlo=12, Thi=25):
+    tmp = tempfile.mkdtemp(prefix='g7_')
+    mapping = {'<sos>': 0, '<eos>': 1}
+    for i in range(2, V):
+        mapping[chr(ord('a') + i)] = i    # <50 symbols, no '#', no '▁' -> unit 'char'
+    with open(os.path.join(tmp, 'mapping.pkl'), 'wb') as f:
+        pickle.dump(mapping, f)
+    data = {}
+    for split, n in sizes:
+        xs, ys = [], []
+        for _ in range(n):
+            T = rng.randint(Tlo, Thi)
+            xs.append(rng.randn(T, D).astype(np.float32))
+            L = rng.randint(2, 5)
+            ys.append([0] + list(rng.randint(2, V, size=L)) + [1])
+        data[split] = (xs, ys)
+        with open(os.path.join(tmp, f'{split}_x.pkl'), 'wb') as f:
+            pickle.dump(xs, f)
+        with open(os.path.join(tmp, f'{split}_y.pkl'), 'wb') as f:
+            pickle.dump(ys, f)
+    return tmp, data
+
+
+_G7_CALLS = []
+
+
+def _g7_hook(m, i, o):
+    _G7_CALLS.append(o)
+
+
+def g7_valid(Writer, out):
+    """Trainer.valid() (solver.py:211-291) on a 6-utterance dev set (two buckets: 4 + 2), initial weights: greedy
+    no-teacher decoding for ans_len + 30 steps (asr.py:101-102), dev_att / dev_ctc / dev_full, error rate, acc, the
+    att_/hyp_/txt_ log entries of the last bucket, best_hyp.txt.  Two models: dot attention-only, and loc + CTC 0.5 with a
+    2-layer Speller whose dropout is 0.3 (must be OFF in valid(): the reference brackets it with eval()/train())."""
+    import yaml
+    import json
+    from src.solver import Trainer
+    def attempt(name, seed):
+        rng = np.random.RandomState(71)
+        V, D = 12, 6
+        tmp, data = _timit_dir(rng, V, D, [('train', 8), ('test', 6)], *((32, 48) if name == 'loc_ctc_drop' else (12, 25)))
+        cfg = yaml.safe_load(open(os.path.join(REF, 'config/timit_example.yaml')))
+        cfg['asr_model']['encoder'].update(dim='8_8_8')
+        cfg['asr_model']['attention'].update(dim=8)
+        cfg['asr_model']['decoder'].update(dim=8)
+        cfg['asr_model']['optimizer'].update(learning_rate=0.001)
+        if name == 'loc_ctc_drop':
+            cfg['asr_model']['optimizer'].update(joint_ctc=0.5)
+            cfg['asr_model']['attention'].update(att_mode='loc')
+            cfg['asr_model']['decoder'].update(layer=2, dropout=0.3)
+        cfg['solver'].update(data_path=tmp, n_jobs=0, batch_size=4, dev_batch_size=4, apex=False,
+                             total_steps=3, tf_start=1.0, tf_end=1.0, dev_step=1000)
+        paras = argparse.Namespace(gpu=False, name='g7', config='config/g7.yaml', seed=0,
+                                   ckpdir=os.path.join(tmp, 'ckpt'), logdir=os.path.join(tmp, 'log'),
+                                   load=None, verbose=False, njobs=1)
+        _seed(seed)
+        Writer.trace.clear(); Writer.texts.clear(); Writer.images.clear()
+        t = Trainer(cfg, paras)
+        t.load_data()
+        t.set_model()
+        with torch.no_grad():                       # sharpen the random-init output layer: argmax margins >> 1e-5
+            t.asr_model.char_trans.weight.mul_(8.0)
+        w0 = _state(t.asr_model, 'w.')
+        calls = _G7_CALLS
+        calls.clear()
+        t.asr_model.register_forward_hook(_g7_hook)      # (module-level: valid() pickles the whole module, solver.py:283)
+        t.valid()
+        assert t.asr_model.training                 # valid() restores train mode (solver.py:287)
+        rec = dict(w0)
+        rows = [(s_, n, k, v) for (s_, n, d) in Writer.trace for k, v in sorted(d.items())]
+        rec['trace_name'] = np.array([r[1] + '/' + r[2] for r in rows])
+        rec['trace_val'] = np.array([r[3] for r in rows], dtype=np.float64)
+        rec['text_name'] = np.array([n for _, n, _ in Writer.texts])
+        rec['text_val'] = np.array([v for _, _, v in Writer.texts])
+        rec['image_name'] = np.array([n for _, n, _ in Writer.images])
+        for i, (_, n, img) in enumerate(Writer.images):
+            rec[f'image{i}'] = img.astype(np.float32)
+        margin = 1e9
+        for i, (ctc_pred, enc_len, att_pred, att_maps) in enumerate(calls):
+            rec[f'call{i}.att_pred'] = _np(att_pred)
+            rec[f'call{i}.att_map'] = _np(att_maps[0])
+            rec[f'call{i}.enc_len'] = np.array(enc_len)
+            if ctc_pred is not None:
+                rec[f'call{i}.ctc_pred'] = _np(ctc_pred)
+            top2 = torch.topk(att_pred, 2, dim=-1).values
+            margin = min(margin, float((top2[..., 0] - top2[..., 1]).min()))
+        rec['n_calls'] = np.array(len(calls))
+        rec['argmax_margin'] = np.array(margin)
+        if margin <= 1e-3 or not all(np.isfinite(r[3]) for r in rows):
+            return None
+        rec['model_seed'] = np.array(seed)
+        rec['best_hyp'] = np.array(open(os.path.join(tmp, 'ckpt', 'g7', 'best_hyp.txt')).read())
+        for split in data:
+            xs, ys = data[split]
+            rec[f'{split}_xlen'] = np.array([len(v) for v in xs])
+            rec[f'{split}_x'] = np.concatenate(xs, 0)
+            rec[f'{split}_ylen'] = np.array([len(v) for v in ys])
+            rec[f'{split}_y'] = np.concatenate([np.array(v) for v in ys])
+        rec['V'] = np.array(V)
+        np.savez(os.path.join(out, f'g7_valid_{name}.npz'), **rec)
+        json.dump(cfg, open(os.path.join(out, f'g7_config_{name}.json'), 'w'), indent=1)
+        return rec
+
+    for name in ['dot_att', 'loc_ctc_drop']:
+        # (first model seed whose greedy argmax margins all exceed 1e-3, so that the token sequence is not decided by rounding)
+        assert any(attempt(name, seed) is not None for seed in range(7, 40)), name
+
+
+# ----------------------------------------------------------------------------- G8 LibriSpeech loader (next-row N4)
+def g8_libri(out):
+    """LoadDataset for the csv + per-utterance .npy format (dataset.py:57-155): bucket membership and order for
+    train / dev / test, incl. a bucket that triggers the half-batch rule by length (> 800 frames), one by label length
+    (> 150), the drop filters (length >= max_timestep, label length >= max_label_len), a trailing partial bucket, ties in
+    length, and the padded tensors of two buckets.  The csv rows are stored so the test rebuilds the directory."""
+    from src.dataset import LoadDataset
+    rng = np.random.RandomState(81)
+    tmp = tempfile.mkdtemp(prefix='g8_')
+    D = 4
+    rows = {}
+    spec = {'train': [900, 850, 820, 805, 640, 640, 640, 500, 410, 400, 399, 380, 300, 300, 250, 1300, 1250, 120, 90, 64, 33, 30],
+            'dev': [700, 650, 610, 90, 80, 70, 60],
+            'test': [55, 801, 47]}
+    for split, lens in spec.items():
+        rr = []
+        os.makedirs(os.path.join(tmp, split), exist_ok=True)
+        order = rng.permutation(len(lens))
+        for k in order:
+            n = lens[k]
+            fp = f'{split}/utt{k:02d}.npy'
+            np.save(os.path.join(tmp, fp), rng.randn(n, D).astype(np.float32))
+            L = int(rng.randint(3, 9))
+            if split == 'train' and n == 410:
+                L = 160                     # half-batch by label length
+            if split == 'train' and n == 33:
+                L = 420                     # dropped: label length >= max_label_len
+            lab = [0] + list(rng.randint(2, 30, size=L)) + [1]
+            rr.append((fp, n, '_'.join(str(v) for v in lab)))
+        rows[split] = rr
+        with open(os.path.join(tmp, split + '.csv'), 'w') as f:
+            f.write('file_path,length,label\n')
+            for r in rr:
+                f.write('%s,%d,%s\n' % r)
+    solver = dict(data_path=tmp, batch_size=4, max_timestep=1200, max_label_len=400, use_gpu=False, n_jobs=0,
+                  dataset='librispeech', train_set=['train'], dev_set=['dev'], test_set=['test'], dev_batch_size=4,
+                  decode_beam_size=1, dev_step=10)
+    rec = {}
+    for split in ['train', 'dev', 'test']:
+        dl = LoadDataset(split, text_only=False, **solver)
+        ds = dl.dataset
+        rec[f'{split}.n_buckets'] = np.array(len(ds))
+        for i in range(len(ds)):
+            rec[f'{split}.bucket{i}.files'] = np.array(ds.X[i])
+            x, y = ds[i]
+            rec[f'{split}.bucket{i}.xshape'] = np.array(x.shape)
+            rec[f'{split}.bucket{i}.y'] = np.asarray(y)
+            if split != 'train' or i in (0, 3):
+                rec[f'{split}.bucket{i}.xsum'] = _np(x.sum(-1))
+        rec[f'{split}.csv'] = np.array(['%s,%d,%s' % r for r in rows[split]])
+    # one more loader with decode_beam_size > 1: test buckets of a single utterance (dataset.py:136)
+    solver['decode_beam_size'] = 5
+    ds = LoadDataset('test', text_only=False, **solver).dataset
+    rec['test_beam.files'] = np.array([v[0] for v in ds.X])
+    rec['D'] = np.array(D)
+    np.savez(os.path.join(out, 'g8_libri_buckets.npz'), **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden'))
@@ -484,6 +655,10 @@ def main():
         g5_prefix(out)
     if want('g6'):
         g6_beam(asr, out)
+    if want('g7'):
+        g7_valid(Writer, out)
+    if want('g8'):
+        g8_libri(out)
     tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
     print('wrote', len(os.listdir(out)), 'files,', tot // 1024, 'KiB ->', out)
 

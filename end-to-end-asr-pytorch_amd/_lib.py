@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
-_SO = os.path.join(_HERE, 'liblas_hip.so')
+_SO = os.path.join(_HERE, os.environ.get('LAS_HIP_LIB', 'liblas_hip.so'))      # (LAS_HIP_LIB: diagnostic builds, tools/ only)
 _HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'las_hip.h')
 _lib = None
 

@@ -274,7 +274,8 @@ class Seq2Seq(nn.Module):
             if self.training and self.dec_dropout > 0:
                 self.drop_calls += 1
                 seed = (seed, self.dec_dropout, (torch.initial_seed() * 2654435761 + self.drop_calls) & 0xffffffff)
-            h_top, att = DecoderFn.apply(enc, psi, enc_len_dev, y, L, self.dec_layers, loc, step_mode, seed, *ws)
+            h_top, att = DecoderFn.apply(enc, psi, enc_len_dev, y, L, self.dec_layers, loc, step_mode,
+                                         dict(seed=seed, status=self.status), *ws)
             logits = ops.linear(h_top, self.P('char_trans.weight'), self.P('char_trans.bias'))     # [L,B,V]
             att_output = ops.Transpose01Fn.apply(logits)
             att_maps = [ops.transpose01(att)]

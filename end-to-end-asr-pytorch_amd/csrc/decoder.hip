@@ -11,6 +11,7 @@
 //           LSTM cells                         skinny MFMA product, cell epilogue
 // Everything needed by the backward pass is kept in caller-owned buffers (las_dec_state).
 #include "las_mma.h"
+#include "decoder_pk.h"
 #include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
@@ -323,6 +324,10 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
                            s.xin, XI, s.tok);
         LAS_LAUNCH_OK();
     }
+    // all steps teacher-forced, one layer, loc attention, no dropout, and the caller provided the workspace: one
+    // persistent launch for the whole loop (decoder_pk.hip); everything else: four launches per step below
+    if (all_teacher && y && !resume && s.pk_ws && s.pk_status && las_dec_pk_fwd_ws_bytes(d) > 0)
+        return las_dec_pk_fwd(d, p, enc, psi, enc_len, st_, st);
     const int NCH = att_chunks(Tp), TC = (Tp + NCH - 1) / NCH, ECH = (E + 63) / 64;
     if (TC > 20) return LAS_E_UNSUPPORTED;
     size_t lds_e = sizeof(float) * (size_t)A;
@@ -412,6 +417,8 @@ extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, c
                                unsigned seed, las_dec_state* st_, void* stream) {
     return decoder_run(d, p, enc, psi, enc_len, y, Ly, step_mode, seed, st_, stream, false);
 }
+
+extern "C" size_t las_decoder_pk_workspace_bytes(const las_dec_dims* d) { return las_dec_pk_fwd_ws_bytes(d); }
 
 extern "C" int las_decoder_step(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                                 const int32_t* enc_len, las_dec_state* st_, float* logits, void* stream) {

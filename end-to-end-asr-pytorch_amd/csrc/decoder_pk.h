@@ -1,0 +1,11 @@
+// Persistent attend-and-spell loops (decoder_pk.hip): ONE launch for all L decode steps instead of 4 launches per step.
+#pragma once
+#include "las_common.h"
+
+// Bytes of las_dec_state.pk_ws a shape needs; 0 = the shape / mode is not handled by the persistent kernels (the
+// per-step launch path of decoder.hip / decoder_bwd.hip runs instead).
+size_t las_dec_pk_fwd_ws_bytes(const las_dec_dims* d);
+// All L teacher-forced steps (location-aware attention, one Speller layer, no dropout).  Preconditions, established by
+// decoder_run: hs/cs slot 0 zeroed, att slot 0 = uniform attention, xin[:, :, 0:C] = embeddings of the fed tokens.
+int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                   const int32_t* enc_len, las_dec_state* st, hipStream_t stream);

@@ -1,0 +1,691 @@
+// Persistent attend-and-spell decoder loop (forward) for gfx950: ONE launch runs all L teacher-forced steps of reference
+// src/asr.py:84-107 (location-aware Attention.forward :443-457, LSTMCell Speller :352-357) instead of four launches per
+// step.  Same arithmetic and the same saved tensors (las_dec_state) as decoder.hip's per-step kernels, so the BPTT of
+// decoder_bwd.hip consumes its output unchanged.
+//
+// The loop is a chain of L dependent steps whose arithmetic is a few microseconds; per-step launches cost ~40 us.  Here
+// every workgroup lives for the whole loop (one per CU, all co-resident) and the step's four data hand-offs go through
+// the L2 / memory fabric with the persistent LSTM's protocol (MI355X_MICROARCH.md "Valid forms", row 1: sc1 stores,
+// every storing wave drains vmcnt(0), workgroup barrier, ONE lane adds to an agent-scope counter; consumers poll with
+// sc1 loads from one wave, barrier, then read the bytes with sc1 loads only).  Two roles:
+//
+//   CELL workgroup (unit slice j of U hidden units, batch slice bs): keeps its 4U rows of [W_hh | W_ih(ctx part)] in LDS
+//     for all steps.  Per step: q_t tile = tanh(W_phi h_{t-1}) (published to the attention workgroups), gates = W_hh
+//     h_{t-1} + W_ih ctx_t + xe_t (xe = W_ih(emb part) emb_t + b_ih: ONE GEMM over all steps before the launch), cell
+//     update, publish h_t, all-gather h_t from the other unit slices of its batch slice.
+//   ATTENTION workgroup (utterance b, part c of NCH): keeps psi[b][its T'-chunk] in REGISTERS (fp32, each thread owns
+//     fixed (frame, a) elements for the whole loop) and enc[b][all T'][its E-slice] in LDS -- nothing of psi / enc is
+//     re-read from HBM or L2 after the prologue (SURVEY.md 8d prices the per-step re-read at 13.5 MB).  Per step:
+//     location conv + tanh(W_lp f) from the previous attention (before q_t arrives, off the critical path), energies of
+//     its T'-chunk once q_t is there, all-gather of the utterance's energies among its NCH parts, softmax (redundantly
+//     per part), context for its E-slice (complete sums: no cross-workgroup reduction), published to the cell role.
+//
+// Hand-offs per step: ctx -> cell, h all-gather (cell), q -> attention, e all-gather (attention).  Spins are bounded; a
+// timeout sets *status = LAS_E_TIMEOUT and every workgroup exits.
+#include "las_mma.h"
+#include "decoder_pk.h"
+#include <stdlib.h>
+#include <stdio.h>
+
+extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                        int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta, float* C, int64_t ldc,
+                        int64_t strideC, const float* bias, int act, int batch, void* stream);
+
+namespace {
+
+constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;     // reference asr.py:395-398
+constexpr int LWP = 208, NSEG = 4, SEGW = LWP / NSEG;              // taps padded with zeros, walked in 4 segments of 52
+constexpr float ATT_SCALE = 2.0f;                                 // reference asr.py:410
+constexpr int PNT = 512, PNW = PNT / 64;
+constexpr unsigned PK_SPIN = 1u << 22;
+constexpr int MAXB = 32, MAXNS = 4;
+constexpr int CLW = 64;                                           // words per counter line: every counter on its own 256 bytes
+constexpr size_t PK_MIN_LDS = 84 * 1024;                          // > 80 KiB: one workgroup per CU
+constexpr size_t PK_LDS_CAP = 160 * 1024;
+
+struct PkSync {                         // zeroed before every launch
+    unsigned abort_[CLW];
+    unsigned cnt_q[MAXNS][CLW];         // per batch slice: q tiles published          (NQC per step)
+    unsigned cnt_h[MAXNS][CLW];         // per batch slice: h unit slices published    (NCT per step)
+    unsigned cnt_e[MAXB][CLW];          // per utterance: energy chunks published      (NCH per step)
+    unsigned cnt_c[MAXB][CLW];          // per utterance: context slices published     (NCH per step)
+};
+
+struct PkGeom {
+    int U, NCT, NS, Bs, NB, NCELL;      // cell role: units per workgroup, unit slices, batch slices, rows per slice, 16-row tiles
+    int NQC;                            // q column tiles (16 wide)
+    int NCH, TC, ES;                    // attention role: parts per utterance, frames per part, context columns per part
+    int Cp, Ep, Cx, Ex;                 // k extents padded to the MFMA k-step; exchange row strides (padded to a vector)
+    int MT, NTW;                        // attention role: 16-frame tiles of a T'-chunk, 16-wide a-tiles per wave
+    size_t lds;
+};
+
+struct PkArgs {
+    int B, Tp, E, A, C, L;
+    PkGeom g;
+    const float* psi; const float* enc; const int32_t* lens;
+    const float* xe;                    // [L][B][4C] W_ih[:, 0:C] emb_t + b_ih
+    const float* w_ih; const float* w_hh; const float* b_hh; const float* w_phi;
+    const float* conv_w; const float* w_lp; const float* w_e; const float* b_e;
+    float* q; float* att; float* xin; float* hs; float* cs; float* gates; float* f; float* s;
+    void* hx; void* cx;                 // exchange rings [2][B][Cx], [2][B][Ex] in the compute type
+    float* ebuf;                        // [2][B][Tp]
+    PkSync* sync; int* status;
+    unsigned long long* dbg;            // [grid][12] cycle sums per phase (stamps build only)
+};
+
+// ---- in-kernel cycle stamps (diagnostic build only: make stamps -> liblas_hip_stamps.so; the product build has none) ----
+#ifdef LAS_PK_STAMPS
+#define PK_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime()
+#define PK_STAMP(i)                                                          \
+    do {                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        st_acc[i] += now_ - st_last;                                         \
+        st_last = now_;                                                      \
+    } while (0)
+#define PK_STAMP_FLUSH(dbg)                                                                          \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && (dbg))                                                               \
+            for (int i_ = 0; i_ < 12; ++i_) (dbg)[(long)blockIdx.x * 12 + i_] = st_acc[i_];          \
+    } while (0)
+#else
+#define PK_STAMP_DECL
+#define PK_STAMP(i)
+#define PK_STAMP_FLUSH(dbg)
+#endif
+
+// ---- hand-off primitives ------------------------------------------------------------------------------------------
+// The LAST wave polls: lane l < n watches counter cnt0 + l*stride (one 4-byte sc1 load per lane and poll).  Result through
+// the LDS word `flag` (callers alternate between two words so that a fast wave cannot overwrite one still being read).
+__device__ __forceinline__ bool pk_block_wait(unsigned* cnt0, int stride, int n, unsigned target, unsigned* abort_word, int* flag) {
+    if (threadIdx.x >= PNT - 64) {
+        const int lane = threadIdx.x & 63;
+        unsigned* p = cnt0 + (long)min(lane, n - 1) * stride;
+        unsigned spins = 0;
+        bool ok = true;
+        while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; break; }
+                if (spins > PK_SPIN) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+            }
+        }
+        if (lane == 0) *flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+// Publish: every storing wave drains its stores, workgroup barrier, one lane adds to the counter.
+__device__ __forceinline__ void pk_signal(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == PNT - 64) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// exchange store of the pair (a, b) at consecutive columns, sc1 (write-through): 4 bytes (bf16) / 8 bytes (f32)
+__device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
+    __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Pull rows x cols (16-byte vectors, sc1 = L1 bypass) of a published tile into LDS; every load of a thread is issued
+// before its first LDS write; out-of-range lanes read through the buffer descriptor's bounds check (0, no branch).
+template <typename T, int VEC, int UNR>
+__device__ __forceinline__ void pk_pull(const T* __restrict__ src, int rows, int cols, int src_ld, T* __restrict__ lds, int ld) {
+    const int vpr = cols / VEC, total = rows * vpr;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows * src_ld * (int)sizeof(T), 0x00020000);
+    for (int i0 = threadIdx.x; i0 < total; i0 += PNT * UNR) {
+        u32x4 v[UNR];
+        int dst[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * PNT;
+            const int r = i / vpr, c = (i - r * vpr) * VEC;
+            dst[u] = i < total ? r * ld + c : -1;
+            const int off = i < total ? (r * src_ld + c) * (int)sizeof(T) : 0x7ffffff0;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (dst[u] >= 0) *(u32x4*)(lds + dst[u]) = v[u];
+    }
+}
+
+// four consecutive LDS values as floats: one 8-byte (bf16) / 16-byte (f32) read
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 v = *(const uint2*)p;
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+
+// ---- cell role ---------------------------------------------------------------------------------------------------
+// LDS: Wl [4U][ld] rows flat = gate*U + unit, columns [0,Cp) = W_hh row, [Cp,Cp+Ep) = W_ih row (context part);
+//      Xl [NB*16][ld] batch rows: [0,Cp) = h_{t-1}, [Cp,Cp+Ep) = ctx_t;  Wq [16][Cp+VEC] my q tile's rows of W_phi;
+//      Gl [8 waves][NB*16][17] accumulators.  Wave w: 16-row tile w % NTILE of Wl, k-steps ks = w / NTILE (mod KP).
+template <int PREC, int NB>
+__device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    const PkGeom& g = a.g;
+    const int j = blockIdx.x / g.NS, bs = blockIdx.x - j * g.NS;
+    const int U = g.U, j0 = j * U, b0 = bs * g.Bs, Bl = min(g.Bs, a.B - b0);
+    const int B = a.B, C = a.C, E = a.E, A = a.A, XI = C + E, Cp = g.Cp, Ep = g.Ep, ld = Cp + Ep + VEC, ldq = Cp + VEC;
+    const int NTILE = 4 * U / 16, KP = PNW / NTILE;
+    T* Wl = (T*)smem;
+    T* Xl = Wl + 4 * U * ld;
+    T* Wq = Xl + NB * 16 * ld;
+    float* Gl = (float*)(Wq + 16 * ldq);
+    int* flag = (int*)(Gl + PNW * NB * 16 * 17);
+    const bool has_q = j < g.NQC;
+
+    for (int i = threadIdx.x; i < 4 * U * ld; i += PNT) {
+        const int k = i % ld, row = i / ld, gi = row / U, n = row - gi * U;
+        float v = 0.f;
+        if (j0 + n < C) {
+            const long wr = (long)gi * C + j0 + n;
+            if (k < C) v = a.w_hh[wr * C + k];
+            else if (k >= Cp && k - Cp < E) v = a.w_ih[wr * XI + C + (k - Cp)];
+        }
+        Wl[i] = to_ct<T>(v);
+    }
+    for (int i = threadIdx.x; i < NB * 16 * ld; i += PNT) Xl[i] = (T)0;
+    for (int i = threadIdx.x; i < 16 * ldq; i += PNT) {
+        const int k = i % ldq, r = i / ldq;
+        Wq[i] = to_ct<T>((has_q && j * 16 + r < A && k < C) ? a.w_phi[(long)(j * 16 + r) * C + k] : 0.f);
+    }
+    __syncthreads();
+
+    // my pointwise element: (batch row, unit)
+    const int er = threadIdx.x / U, en = threadIdx.x - er * U, ej = j0 + en;
+    const bool ev = er < Bl && ej < C && threadIdx.x < NB * 16 * U;
+    float c_state = 0.f, bias[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = ev ? a.b_hh[gi * C + ej] : 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    const int tile = wave % NTILE, kp = wave / NTILE;
+    unsigned* abort_word = a.sync->abort_;
+    unsigned nwait = 0;
+    T* hx = (T*)a.hx;
+    T* cx = (T*)a.cx;
+    PK_STAMP_DECL;
+
+    for (int t = 0; t < a.L; ++t) {
+        // ---- (1) q_t tile = tanh(W_phi[16 j .. ] h_{t-1}) for my batch slice; t = 0: h = 0
+        if (has_q) {
+            f32x4 qa[NB];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) qa[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t > 0)
+                for (int ks = wave; ks < Cp / KSTEP; ks += PNW) mma_rows<PREC, NB>(qa, Xl + ks * KSTEP, ld, Wq + ks * KSTEP, ldq, 1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = qa[bt][r];
+            __syncthreads();
+            if (threadIdx.x < NB * 16 * 16) {
+                const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < PNW; ++w) v += Gl[(w * NB * 16 + row) * 17 + col];
+                if (row < Bl && j * 16 + col < A) st_sc1(a.q + ((long)t * B + b0 + row) * A + j * 16 + col, fast_tanh(v));
+            }
+            pk_signal(&a.sync->cnt_q[bs][0]);
+        }
+        PK_STAMP(0);
+        // ---- (2) recurrent half of the gates; the embedding half + b_ih comes precomputed
+        float xe[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) xe[gi] = ev ? a.xe[((long)t * B + b0 + er) * 4 * C + gi * C + ej] : 0.f;
+        f32x4 acc[NB];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t > 0)
+            for (int ks = kp; ks < Cp / KSTEP; ks += KP) mma_rows<PREC, NB>(acc, Xl + ks * KSTEP, ld, Wl + tile * 16 * ld + ks * KSTEP, ld, 1);
+        PK_STAMP(1);
+        // ---- (3) context of this step from the attention workgroups of my batch rows
+        if (!pk_block_wait(&a.sync->cnt_c[b0][0], CLW, Bl, (unsigned)g.NCH * (t + 1), abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(2);
+        pk_pull<T, VEC, 4>(cx + ((long)(t & 1) * B + b0) * g.Ex, Bl, g.Ex, g.Ex, Xl + Cp, ld);
+        __syncthreads();
+        for (int ks = kp; ks < Ep / KSTEP; ks += KP) mma_rows<PREC, NB>(acc, Xl + Cp + ks * KSTEP, ld, Wl + tile * 16 * ld + Cp + ks * KSTEP, ld, 1);
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = acc[bt][r];
+        __syncthreads();
+        PK_STAMP(3);
+        // ---- (4) cell update (reference asr.py:353: nn.LSTMCell, gate order i,f,g,o); publish h_t first
+        float pre[4];
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int flat = gi * U + en, tl = flat >> 4, col = flat & 15;
+            float v = xe[gi] + bias[gi];
+            for (int k = 0; k < KP; ++k) v += Gl[((tl + NTILE * k) * NB * 16 + min(er, NB * 16 - 1)) * 17 + col];
+            pre[gi] = v;
+        }
+        const float ig = fast_sig(pre[0]), fg = fast_sig(pre[1]), gg = fast_tanh(pre[2]), og = fast_sig(pre[3]);
+        const float cn = fg * c_state + ig * gg;
+        const float hn = ev ? og * fast_tanh(cn) : 0.f;
+        c_state = cn;
+        const float hnext = las_dpp<0x101, 0xf>(0.f, hn);               // unit en + 1 (U is even, so pairs never straddle rows)
+        if (ev && !(en & 1)) st_pair_sc1(hx + ((long)(t & 1) * B + b0 + er) * g.Cx + ej, hn, hnext);
+        pk_signal(&a.sync->cnt_h[bs][0]);
+        PK_STAMP(4);
+        if (ev) {
+            const long ro = (long)t * B + b0 + er;
+            __builtin_nontemporal_store(hn, &a.hs[(ro + B) * C + ej]);          // slot t + 1
+            __builtin_nontemporal_store(cn, &a.cs[(ro + B) * C + ej]);
+            float* go = a.gates + ro * 4 * C;
+            __builtin_nontemporal_store(ig, &go[ej]);
+            __builtin_nontemporal_store(fg, &go[C + ej]);
+            __builtin_nontemporal_store(gg, &go[2 * C + ej]);
+            __builtin_nontemporal_store(og, &go[3 * C + ej]);
+        }
+        PK_STAMP(5);
+        // ---- (5) all-gather h_t of my batch slice for the next step
+        if (t + 1 < a.L) {
+            if (!pk_block_wait(&a.sync->cnt_h[bs][0], 0, 1, (unsigned)g.NCT * (t + 1), abort_word, flag + (nwait++ & 1))) {
+                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                return;
+            }
+            PK_STAMP(6);
+            pk_pull<T, VEC, 2>(hx + ((long)(t & 1) * B + b0) * g.Cx, Bl, g.Cx, g.Cx, Xl, ld);
+            __syncthreads();
+            PK_STAMP(7);
+        }
+    }
+    PK_STAMP_FLUSH(a.dbg);
+}
+
+// ---- attention role ----------------------------------------------------------------------------------------------
+// MT = 16-frame tiles of my T'-chunk, NTW = 16-wide a-tiles per wave (wave w owns a-tiles w, w+8, ...).  u = tanh(F W_lp^T)
+// is an MFMA product (F: frames x 10 channels from the location conv, zero padded to one k-step), and psi / u / s live in
+// registers in that product's output layout: lane (fr = lane & 15, fq = lane >> 4) holds frames 16 mt + 4 fq + r, r = 0..3,
+// of a = 16 (wave + 8 j) + fr.
+template <int PREC, int MT, int NTW>
+__device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
+    const PkGeom& g = a.g;
+    const int id = blockIdx.x - g.NCELL, b = id / g.NCH, c = id - b * g.NCH;
+    const int bs = b / g.Bs;
+    const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E;
+    const int len = a.lens[b];
+    const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0));
+    const int ES = g.ES, e0 = c * ES, ESr = max(0, min(ES, E - e0)), ESp = ES + 4;
+    const int NQ4 = ES / 4, NTG = min(32, PNT / NQ4);
+    const int TCq = (TC + 3) / 4, A4 = (A + 3) & ~3, Tp4 = (Tp + 3) & ~3;
+    // every float array below starts 16-byte aligned (sizes are multiples of 4 floats): the location conv reads 16 bytes a time
+    T* enc_l = (T*)smem;                                         // [Tp][ESp]
+    float* part_l = (float*)(smem + (((size_t)Tp * ESp * sizeof(T) + 15) & ~(size_t)15));     // [NTG][ES]
+    float* cw_l = part_l + NTG * ES;                             // [10][LWP] conv taps, zero padded to 208
+    float* att_l = cw_l + LOC_C * LWP;                           // [<=3 | LOC_K | Tp | LOC_K + 16] previous attention, zero margins
+    float* f4_l = att_l + Tp4 + 2 * LOC_K + 20;                  // [4 tap segments][10][TCq][4] partial conv sums
+    float* we_l = f4_l + NSEG * LOC_C * TCq * 4;                 // [A4]
+    float* q_l = we_l + A4;                                      // [A4]
+    float* e_l = q_l + A4;                                       // [Tp4]
+    float* ep_l = e_l + Tp4;                                     // [8 waves][MT*16] partial energies
+    float* red = ep_l + PNW * MT * 16;                           // [64]
+    int* flag = (int*)(red + 64);                                // [4]
+    T* Ft = (T*)(flag + 4);                                      // [MT*16][LDK] location features of my frames (frames x channels)
+    T* Wt = Ft + MT * 16 * LDK;                                  // [NTW*8*16][LDK] W_lp rows (a x channels), zero padded
+    // my copy of the attention is shifted so that frame r0 sits on a 16-byte boundary: att0[LOC_K + t'] = att[t']
+    float* att0 = att_l + ((4 - ((r0 + LOC_K) & 3)) & 3);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+
+    // ---- prologue: everything of psi / enc this workgroup will ever need
+    float pv[MT][NTW][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tp = min(r0 + mt * 16 + fq * 4 + r, Tp - 1), aa = min((wave + PNW * j) * 16 + fr, A - 1);
+                pv[mt][j][r] = a.psi[((long)b * Tp + tp) * A + aa];
+            }
+    for (int i = threadIdx.x; i < Tp * ESp; i += PNT) {
+        const int tp = i / ESp, col = i - tp * ESp;
+        enc_l[i] = to_ct<T>((col < ESr && tp < len) ? a.enc[((long)b * Tp + tp) * E + e0 + col] : 0.f);
+    }
+    for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
+        const int k = i % LDK, aa = i / LDK;
+        Wt[i] = to_ct<T>((k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+    }
+    for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
+    for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) cw_l[i] = 0.f;
+    __syncthreads();
+    fill_batched<4>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { const int cc = i / LOC_W; cw_l[cc * LWP + (i - cc * LOC_W)] = v; });
+    fill_batched<2>(a.w_e, A, [&](int i, float v) { we_l[i] = v; });
+    for (int i = threadIdx.x; i < Tp4 + 2 * LOC_K + 20; i += PNT) att_l[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += PNT) att0[LOC_K + i] = 1.f / (float)len;      // reference asr.py:444-449
+    __syncthreads();
+    float wev[NTW];                                              // my a-columns' energy weights (0 beyond A)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? we_l[aa] : 0.f; }
+    const float be = a.b_e[0];
+    unsigned* abort_word = a.sync->abort_;
+    unsigned nwait = 0;
+    T* cx = (T*)a.cx;
+    // this thread's (first) conv work item and reduction element: fixed for the whole loop
+    const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
+              cv_qd = threadIdx.x - cv_sg * (LOC_C * TCq) - cv_cc * TCq;
+    const int rd_cc = threadIdx.x / TC, rd_tt = threadIdx.x - rd_cc * TC;
+    PK_STAMP_DECL;
+
+    for (int t = 0; t < a.L; ++t) {
+        // ---- (A) location features of my frames from the previous attention, u = tanh(W_lp f): needs no q_t.
+        // Work item = (channel, 4 consecutive frames, tap segment): 16 FMAs per three 16-byte LDS reads (the scalar form
+        // -- two 4-byte reads per FMA -- was bound by LDS instruction issue: 9 400 cycles a step, cycle stamps)
+        for (int i = threadIdx.x; i < NSEG * LOC_C * TCq; i += PNT) {
+            int sg = cv_sg, cc = cv_cc, qd = cv_qd;                          // (the first item's split is loop-invariant)
+            if (i >= PNT) { sg = i / (LOC_C * TCq); const int rem = i - sg * (LOC_C * TCq); cc = rem / TCq; qd = rem - cc * TCq; }
+            if (4 * qd >= TCr) { *(float4*)(f4_l + (size_t)i * 4) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            const float* w = cw_l + cc * LWP + sg * SEGW;
+            const float* p = att0 + r0 + 4 * qd + sg * SEGW;                 // p[k] = prev[r0 + 4 qd + (52 sg + k) - LOC_K]
+            float4 lo = *(const float4*)p;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < SEGW; k += 4) {
+                const float4 wv = *(const float4*)(w + k), hi = *(const float4*)(p + k + 4);
+                // (explicit fma: the library is built with -ffp-contract=off, a*b+c would be two instructions)
+                o0 = fmaf(wv.x, lo.x, fmaf(wv.y, lo.y, fmaf(wv.z, lo.z, fmaf(wv.w, lo.w, o0))));
+                o1 = fmaf(wv.x, lo.y, fmaf(wv.y, lo.z, fmaf(wv.z, lo.w, fmaf(wv.w, hi.x, o1))));
+                o2 = fmaf(wv.x, lo.z, fmaf(wv.y, lo.w, fmaf(wv.z, hi.x, fmaf(wv.w, hi.y, o2))));
+                o3 = fmaf(wv.x, lo.w, fmaf(wv.y, hi.x, fmaf(wv.z, hi.y, fmaf(wv.w, hi.z, o3))));
+                lo = hi;
+            }
+            *(float4*)(f4_l + (size_t)i * 4) = make_float4(o0, o1, o2, o3);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+            int cc = rd_cc, tt = rd_tt;
+            if (i >= PNT) { cc = i / TC; tt = i - cc * TC; }
+            float v = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) v += f4_l[(((size_t)sg * LOC_C + cc) * TCq + (tt >> 2)) * 4 + (tt & 3)];
+            Ft[tt * LDK + cc] = to_ct<T>(v);
+            if (tt < TCr) __builtin_nontemporal_store(v, &a.f[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt]);
+        }
+        __syncthreads();
+        PK_STAMP(0);
+        // u = tanh(F W_lp^T): one MFMA k-step per (frame tile, a tile); kept in registers until q_t arrives
+        float uv[MT][NTW][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+                mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uv[mt][j][r] = fast_tanh(acc[0][r]);
+                    asm volatile("" : "+v"(uv[mt][j][r]));        // done HERE, before the wait for q_t (not sunk behind it)
+                }
+            }
+        PK_STAMP(1);
+        // ---- (B) q_t from the cell workgroups of my batch slice
+        if (!pk_block_wait(&a.sync->cnt_q[bs][0], 0, 1, (unsigned)g.NQC * (t + 1), abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(2);
+        float qv[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) qv[j] = ld_sc1(a.q + ((long)t * B + b) * A + min((wave + PNW * j) * 16 + fr, A - 1));
+        // ---- (C) energies of my frames: e = w_e . tanh(psi + q + u) + b_e   (reference asr.py:453); s overwrites u
+        float er_[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const float sv = fast_tanh(pv[mt][j][r] + qv[j] + uv[mt][j][r]);
+                    uv[mt][j][r] = sv;
+                    acc = fmaf(wev[j], sv, acc);
+                }
+                // sum over the 16 a's of my lane row (DPP row_shr 1, 2, 4, 8: lane 15 of the row ends with the total)
+                acc += las_dpp<0x111, 0xf>(0.f, acc);
+                acc += las_dpp<0x112, 0xf>(0.f, acc);
+                acc += las_dpp<0x114, 0xf>(0.f, acc);
+                acc += las_dpp<0x118, 0xf>(0.f, acc);
+                er_[mt][r] = acc;
+            }
+        if (fr == 15) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ep_l[wave * MT * 16 + mt * 16 + fq * 4 + r] = er_[mt][r];
+        }
+        __syncthreads();
+        if (threadIdx.x < TCr) {
+            float v = be;
+#pragma unroll
+            for (int w = 0; w < PNW; ++w) v += ep_l[w * MT * 16 + threadIdx.x];
+            st_sc1(a.ebuf + ((long)(t & 1) * B + b) * Tp + r0 + threadIdx.x, r0 + (int)threadIdx.x < len ? v : 0.f);
+        }
+        pk_signal(&a.sync->cnt_e[b][0]);
+        PK_STAMP(3);
+        PK_STAMP(4);
+        // ---- (D) all energies of my utterance; masked softmax(2 e) (reference asr.py:454-455), redundantly per part
+        if (!pk_block_wait(&a.sync->cnt_e[b][0], 0, 1, (unsigned)g.NCH * (t + 1), abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(5);
+        float m = -INFINITY;
+        for (int i = threadIdx.x; i < len; i += PNT) {
+            const float v = ATT_SCALE * ld_sc1(a.ebuf + ((long)(t & 1) * B + b) * Tp + i);
+            e_l[i] = v;
+            m = fmaxf(m, v);
+        }
+        m = block_max(m, red);
+        float sum = 0.f;
+        for (int i = threadIdx.x; i < len; i += PNT) { const float v = expf(e_l[i] - m); e_l[i] = v; sum += v; }
+        sum = block_sum(sum, red);
+        const float inv = 1.f / sum;
+        for (int i = threadIdx.x; i < Tp; i += PNT) att0[LOC_K + i] = i < len ? e_l[i] * inv : 0.f;
+        __syncthreads();
+        PK_STAMP(6);
+        // ---- (E) context of my E-slice over the RAW encoder features (reference asr.py:457); complete sums
+        {
+            const int cq = threadIdx.x % NQ4, tg = threadIdx.x / NQ4;
+            if (tg < NTG) {
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+                for (int tp = tg; tp < len; tp += NTG) {
+                    const float w = att0[LOC_K + tp];
+                    const float4 v = ld4(enc_l + (size_t)tp * ESp + cq * 4);
+                    c0 = fmaf(w, v.x, c0); c1 = fmaf(w, v.y, c1); c2 = fmaf(w, v.z, c2); c3 = fmaf(w, v.w, c3);
+                }
+                *(float4*)(part_l + tg * ES + cq * 4) = make_float4(c0, c1, c2, c3);
+            }
+        }
+        __syncthreads();
+        {
+            const int col = threadIdx.x;
+            float v = 0.f;
+            if (col < ES) for (int tg = 0; tg < NTG; ++tg) v += part_l[tg * ES + col];
+            const float vnext = las_dpp<0x101, 0xf>(0.f, v);
+            if (col < ESr && !(col & 1)) st_pair_sc1(cx + ((long)(t & 1) * B + b) * g.Ex + e0 + col, v, col + 1 < ESr ? vnext : 0.f);
+            pk_signal(&a.sync->cnt_c[b][0]);
+            PK_STAMP(7);
+            // saved for the backward pass (after the hand-off): the context, and the attention map from part 0
+            if (col < ESr) a.xin[((long)t * B + b) * XI + C + e0 + col] = v;
+            if (c == 0)
+                for (int i = threadIdx.x; i < Tp; i += PNT) a.att[((long)(t + 1) * B + b) * Tp + i] = att0[LOC_K + i];
+        }
+        // s = tanh(psi + q + u) of my frames, saved for the backward pass: stored only now, after both hand-offs of the
+        // step, so that neither waits for these stores (write-only stream: non-temporal)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tt = mt * 16 + fq * 4 + r, tp = r0 + tt;
+                if (tt < TCr && tp < len) {
+                    float* __restrict__ so = a.s + (((long)t * B + b) * Tp + tp) * A;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const int aa = (wave + PNW * j) * 16 + fr;
+                        if (aa < A) __builtin_nontemporal_store(uv[mt][j][r], &so[aa]);
+                    }
+                }
+            }
+        PK_STAMP(8);
+    }
+    PK_STAMP_FLUSH(a.dbg);
+}
+
+template <int PREC, int NB, int MT, int NTW>
+__global__ __launch_bounds__(PNT) void dec_pk_fwd_kernel(PkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < a.g.NCELL) pk_cell_role<PREC, NB>(a, smem);
+    else pk_att_role<PREC, MT, NTW>(a, smem);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t cell_lds(int prec, const PkGeom& g, int C, int E) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4;
+    const size_t ld = g.Cp + g.Ep + vec;
+    return (size_t)(4 * g.U + g.NB * 16) * ld * sz + (size_t)16 * (g.Cp + vec) * sz + sizeof(float) * PNW * g.NB * 16 * 17 + 64;
+}
+size_t att_lds(int prec, const PkGeom& g, int Tp, int A) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, ldk = prec == LAS_PREC_BF16 ? 40 : 20;
+    int ntg = PNT / (g.ES / 4);
+    if (ntg > 32) ntg = 32;
+    const size_t A4 = (A + 3) & ~3, Tp4 = (Tp + 3) & ~3, TCq = (g.TC + 3) / 4;
+    return (size_t)Tp * (g.ES + 4) * sz + 16 + (size_t)(g.MT * 16 + g.NTW * PNW * 16) * ldk * sz +
+           sizeof(float) * ((size_t)ntg * g.ES + LOC_C * LWP + (Tp4 + 2 * LOC_K + 20) + NSEG * LOC_C * TCq * 4 + 2 * A4 + Tp4 +
+                            PNW * g.MT * 16 + 64 + 4) + 64;
+}
+
+bool pk_geom(const las_dec_dims* d, PkGeom& best) {
+    if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
+    if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
+    if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
+    if (getenv("LAS_DEC_NO_PK")) return false;
+    const int ks = d->prec == LAS_PREC_BF16 ? 32 : 16, vec = d->prec == LAS_PREC_BF16 ? 8 : 4;
+    int want_ns = 0, want_u = 0;
+    if (const char* e = getenv("LAS_DEC_PK_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);     // (A/B measurements)
+    static const int cand[6][2] = {{2, 8}, {2, 16}, {1, 8}, {1, 16}, {2, 4}, {1, 4}};
+    for (int ci = 0; ci < 6; ++ci) {
+        PkGeom g{};
+        g.NS = cand[ci][0]; g.U = cand[ci][1];
+        if (want_ns && (g.NS != want_ns || g.U != want_u)) continue;
+        if (g.NS > 1 && d->B < 8) continue;
+        g.Bs = (d->B + g.NS - 1) / g.NS;
+        g.NS = (d->B + g.Bs - 1) / g.Bs;
+        g.NB = g.Bs <= 16 ? 1 : 2;
+        if (g.Bs > 32) continue;
+        g.NCT = (d->C + g.U - 1) / g.U;
+        g.NCELL = g.NCT * g.NS;
+        g.NQC = (d->A + 15) / 16;
+        if (g.NQC > g.NCT) continue;
+        g.Cp = (d->C + ks - 1) / ks * ks; g.Ep = (d->E + ks - 1) / ks * ks;
+        g.Cx = (d->C + vec - 1) / vec * vec; g.Ex = (d->E + vec - 1) / vec * vec;
+        if (cell_lds(d->prec, g, d->C, d->E) > PK_LDS_CAP) continue;
+        g.NCH = (256 - g.NCELL) / d->B;
+        if (g.NCH > 16) g.NCH = 16;
+        if (g.NCH < 1) continue;
+        g.TC = (d->Tp + g.NCH - 1) / g.NCH;
+        if (g.TC > 64) continue;
+        g.MT = g.TC <= 32 ? 2 : g.TC <= 48 ? 3 : 4;
+        g.NTW = d->A <= 128 ? 1 : d->A <= 384 ? 3 : 4;
+        if (g.NTW == 4 && g.MT == 4) continue;          // (register budget of the attention role: 2 x 4 MT NTW values per lane)
+        g.ES = ((d->E + g.NCH - 1) / g.NCH + 3) / 4 * 4;
+        if (g.ES / 4 > PNT || g.ES > PNT) continue;
+        if (att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
+        g.lds = cell_lds(d->prec, g, d->C, d->E);
+        const size_t al = att_lds(d->prec, g, d->Tp, d->A);
+        if (al > g.lds) g.lds = al;
+        if (g.lds < PK_MIN_LDS) g.lds = PK_MIN_LDS;
+        best = g;
+        return true;
+    }
+    return false;
+}
+
+struct WsLayout { size_t sync, hx, cx, ebuf, dbg, xe, total; };
+WsLayout ws_layout(const las_dec_dims* d, const PkGeom& g) {
+    const size_t sz = d->prec == LAS_PREC_BF16 ? 2 : 4;
+    WsLayout w;
+    size_t o = 0;
+    w.sync = o; o += las_align(sizeof(PkSync));
+    w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 12);      // (read by tools/pk_stamps.py in the stamps build)
+    w.hx = o; o += las_align((size_t)2 * d->B * g.Cx * sz);
+    w.cx = o; o += las_align((size_t)2 * d->B * g.Ex * sz);
+    w.ebuf = o; o += las_align(sizeof(float) * 2 * d->B * d->Tp);
+    w.xe = o; o += las_align(sizeof(float) * (size_t)d->L * d->B * 4 * d->C);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+size_t las_dec_pk_fwd_ws_bytes(const las_dec_dims* d) {
+    PkGeom g;
+    if (!pk_geom(d, g)) return 0;
+    return ws_layout(d, g).total;
+}
+
+int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                   const int32_t* enc_len, las_dec_state* st, hipStream_t stream) {
+    PkGeom g;
+    if (!pk_geom(d, g)) return LAS_E_UNSUPPORTED;
+    LAS_CHECK_ARG(st->pk_ws && st->pk_status && st->f && st->s && p->conv_w && p->w_lp && p->w_e && p->b_e);
+    const WsLayout w = ws_layout(d, g);
+    char* ws = (char*)st->pk_ws;
+    const int B = d->B, C = d->C, E = d->E, XI = C + E, L = d->L;
+    // counters, exchange rings (their pad columns must read as zero) and the energy ring
+    LAS_HIP(hipMemsetAsync(ws, 0, w.xe, stream));
+    // xe[t][b][:] = W_ih[:, 0:C] emb(tok[t][b]) + b_ih for every step: one MFMA GEMM instead of L skinny k-segments
+    float* xe = (float*)(ws + w.xe);
+    int rc = las_gemm(d->prec, 0, 1, L * B, 4 * C, C, 1.f, st->xin, XI, 0, p->w_ih[0], XI, 0, 0.f, xe, 4 * C, 0, p->b_ih[0], 0, 1,
+                      (void*)stream);
+    if (rc) return rc;
+    PkArgs a{};
+    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g;
+    a.psi = psi; a.enc = enc; a.lens = enc_len; a.xe = xe;
+    a.w_ih = p->w_ih[0]; a.w_hh = p->w_hh[0]; a.b_hh = p->b_hh[0]; a.w_phi = p->w_phi;
+    a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e; a.b_e = p->b_e;
+    a.q = st->q; a.att = st->att; a.xin = st->xin; a.hs = st->hs; a.cs = st->cs; a.gates = st->gates; a.f = st->f; a.s = st->s;
+    a.hx = ws + w.hx; a.cx = ws + w.cx; a.ebuf = (float*)(ws + w.ebuf);
+    a.sync = (PkSync*)(ws + w.sync); a.status = st->pk_status;
+    a.dbg = (unsigned long long*)(ws + w.dbg);
+    const int grid = g.NCELL + B * g.NCH;
+#define LAS_PK_GO(P_, N_, M_, W_)                                                                                  \
+    {                                                                                                             \
+        auto k = dec_pk_fwd_kernel<P_, N_, M_, W_>;                                                               \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PNT), g.lds, stream, a);                                           \
+        LAS_LAUNCH_OK();                                                                                          \
+        return LAS_OK;                                                                                            \
+    }
+#define LAS_PK_W(P_, N_, M_)                                                                                       \
+    {                                                                                                             \
+        if (g.NTW == 1) LAS_PK_GO(P_, N_, M_, 1) else if (g.NTW == 3) LAS_PK_GO(P_, N_, M_, 3) else LAS_PK_GO(P_, N_, M_, 4) \
+    }
+#define LAS_PK_AI(P_, N_)                                                                                          \
+    {                                                                                                             \
+        if (g.MT == 2) LAS_PK_W(P_, N_, 2) else if (g.MT == 3) LAS_PK_W(P_, N_, 3) else LAS_PK_W(P_, N_, 4)        \
+    }
+    if (d->prec == LAS_PREC_BF16) { if (g.NB == 1) LAS_PK_AI(LAS_PREC_BF16, 1) else LAS_PK_AI(LAS_PREC_BF16, 2) }
+    else { if (g.NB == 1) LAS_PK_AI(LAS_PREC_F32, 1) else LAS_PK_AI(LAS_PREC_F32, 2) }
+#undef LAS_PK_W
+#undef LAS_PK_AI
+#undef LAS_PK_GO
+    return LAS_E_BADARG;
+}

@@ -47,7 +47,7 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NB], const typename CT<PRE
 // tanh through one v_exp: |abs err| ~1e-7, used where the argument is already O(1) noise-limited.
 __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(2.f * x);
-    return 1.f - 2.f / (e + 1.f);
+    return 1.f - __fdividef(2.f, e + 1.f);        // v_rcp + v_mul: the IEEE division here was 12 instructions per tanh
 }
 
 // Cell pointwise backward of the EARLIER decode step, fused into the skinny product that yields its recurrent dh

@@ -23,7 +23,7 @@ class DecParams(ctypes.Structure):
 
 class DecState(ctypes.Structure):
     _fields_ = [('tok', P), ('xin', P), ('q', P), ('att', P), ('hs', P), ('cs', P), ('gates', P), ('f', P), ('s', P),
-                ('ebuf', P), ('logits_step', P), ('xdrop', P), ('hdrop', P)]
+                ('ebuf', P), ('logits_step', P), ('xdrop', P), ('hdrop', P), ('pk_ws', P), ('pk_status', P)]
 
 
 def _p(t):
@@ -69,7 +69,10 @@ def make_params(W, NL, loc, transposed=None, packed=None):
     return p
 
 
-def alloc_state(dims, dev):
+def alloc_state(dims, dev, status=None, persistent=True):
+    """Saved-state tensors of one decode loop.  persistent: also the workspace of the one-launch loop (decoder_pk.hip) when
+    the shape / mode is eligible (las_decoder_pk_workspace_bytes > 0); status: int32 [1] device tensor that a hand-off
+    timeout of that launch is reported in (the model's, so that the Trainer's check sees it)."""
     d = dims
     f32 = dict(dtype=torch.float32, device=dev)
     S = dict(
@@ -90,13 +93,19 @@ def alloc_state(dims, dev):
         S['xdrop'] = torch.empty(d.L, d.B, d.C + d.E, **f32)
         if d.NL > 1:
             S['hdrop'] = torch.empty(d.NL, d.L, d.B, d.C, **f32)
+    if persistent:
+        nbytes = _lib.lib().las_decoder_pk_workspace_bytes(ctypes.byref(d))
+        if nbytes:
+            S['pk_ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            S['pk_status'] = status if status is not None else torch.zeros(1, dtype=torch.int32, device=dev)
     st = DecState()
     for k, v in S.items():
         setattr(st, k, v.data_ptr())
     return S, st
 
 
-def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, seed=0, dropout=0.0, drop_seed=0):
+def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, seed=0, dropout=0.0, drop_seed=0, status=None,
+                        persistent=True):
     """Runs las_decoder_fwd; returns the dict of saved-state tensors (used by tests and by DecoderFn)."""
     L_ = _lib.lib()
     B, Tp, E = enc.shape
@@ -109,7 +118,7 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
         for l in range(NL):
             packed[f'cell{l}'] = pack_weights([W[f'decoder.layer{l}.weight_ih'], W[f'decoder.layer{l}.weight_hh']], 4 * C, cell_C=C)
     params = make_params(W, NL, loc, packed=packed)
-    S, st = alloc_state(dims, enc.device)
+    S, st = alloc_state(dims, enc.device, status, persistent and step_mode is None and y is not None)
     S['_packed'] = packed
     sm = None
     if step_mode is not None:
@@ -158,13 +167,16 @@ class DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, *weights):
+        status = None
+        if isinstance(seed, dict):                       # (seed, status tensor[, dropout, drop_seed]) from Seq2Seq.forward
+            status, seed = seed.get('status'), seed['seed']
         names = weight_names(NL, loc)
         W = dict(zip(names, weights))
         enc, psi = enc.contiguous(), psi.contiguous()
         dropout, drop_seed = 0.0, 0
         if isinstance(seed, tuple):
             seed, dropout, drop_seed = seed
-        S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, dropout, drop_seed)
+        S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, dropout, drop_seed, status=status)
         ctx.S, ctx.W, ctx.cfg = S, W, (L, NL, loc, names)
         ctx.save_for_backward(enc, psi, enc_len)
         h_top = S['hs'][NL - 1, 1:]

@@ -154,7 +154,12 @@ typedef struct {                    /* saved activations, written by fwd, read b
     float* logits_step;             /* [B][V] scratch (sampled / greedy steps) */
     float* xdrop;                   /* dropout > 0: [L][B][C+E] cell-0 input after dropout (xin keeps the clean one) */
     float* hdrop;                   /* dropout > 0, NL > 1: [NL][L][B][C] recurrent state of layers >= 1 after dropout */
+    void* pk_ws;                    /* las_decoder_pk_workspace_bytes(dims) bytes, or NULL: with it, a teacher-forced loc-attention
+                                       loop with one Speller layer and no dropout runs as ONE persistent launch (decoder_pk.hip) */
+    int32_t* pk_status;             /* int32, caller-zeroed: set to LAS_E_TIMEOUT if a hand-off spin of that launch ran out */
 } las_dec_state;
+/* 0: this shape / mode always takes the per-step launch path */
+size_t las_decoder_pk_workspace_bytes(const las_dec_dims* dims);
 /* step_mode[t] (host): how the token fed at step t is chosen: 1 teacher y[:,t], 0 sampled from softmax of
  * step t-1's logits, 2 argmax of step t-1's logits.  step_mode==NULL means all teacher.  y [B][Ly] int64. */
 int las_decoder_fwd(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,

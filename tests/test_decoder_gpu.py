@@ -213,3 +213,45 @@ def test_decoder_dropout(mods, NL):
     for k in names:
         if not k.startswith('char_trans'):
             near(Wg[k].grad, Wt[k].grad, k)
+
+
+@pytest.mark.parametrize('prec,B,Tp,E,A,C,V,L', [('f32', 5, 150, 48, 40, 32, 31, 6), ('bf16', 5, 150, 48, 40, 32, 31, 6),
+                                                 ('f32', 12, 77, 96, 130, 64, 17, 5), ('f32', 3, 9, 10, 7, 6, 9, 4),
+                                                 ('bf16', 24, 300, 640, 300, 320, 31, 9), ('bf16', 12, 300, 640, 300, 320, 31, 5),
+                                                 ('bf16', 30, 201, 256, 512, 128, 40, 4)])
+def test_persistent_loop_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L):
+    """The one-launch loop (decoder_pk.hip: cell / attention roles handing off through the L2) against the four
+    launches per step of decoder.hip on the same inputs: every saved tensor the backward pass reads.  f32: 2e-5 (only
+    summation orders differ); bf16: 2e-2 (the persistent loop additionally keeps enc and the exchanged h / ctx in bf16,
+    the MFMA operand format of this mode).  Shapes: several T'-chunks and E-slices per utterance incl. empty ones, the
+    C2 / C3 decoder (B = 24 as two batch slices, and the half batch 12), B = 30 with A = 512 (two batch tiles per slice)."""
+    ops, dec = mods
+    rng = np.random.RandomState(B * 1000 + Tp + L)
+    W = rand_weights(rng, V, C, E, A, 1, True)
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    Wg = {k: torch.tensor(v, device=DEV) for k, v in W.items()}
+    args = (Wg, torch.tensor(enc, device=DEV), torch.tensor(psi, device=DEV), torch.tensor(lens, dtype=torch.int32, device=DEV),
+            torch.tensor(y, device=DEV), L, 1, True)
+    ops.set_precision(prec)
+    try:
+        S1 = dec.decoder_forward_raw(*args, persistent=True)
+        S0 = dec.decoder_forward_raw(*args, persistent=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('bf16')
+    assert 'pk_ws' in S1 and 'pk_ws' not in S0, 'the persistent launch must be the path taken for this shape'
+    assert int(S1['pk_status'].item()) == 0
+    tol = dict(atol=2e-5, rtol=1e-4) if prec == 'f32' else dict(atol=2e-2, rtol=2e-2)
+    for k in ['q', 'att', 'xin', 'hs', 'cs', 'gates', 'f', 's']:
+        a1, a0 = S1[k].cpu().numpy(), S0[k].cpu().numpy()
+        if k == 's':                                   # only frames inside the utterance are defined
+            for b, l in enumerate(lens):
+                np.testing.assert_allclose(a1[:, b, :l], a0[:, b, :l], err_msg=k, **tol)
+        else:
+            np.testing.assert_allclose(a1, a0, err_msg=k, **tol)
+    assert np.array_equal(S1['tok'].cpu().numpy(), S0['tok'].cpu().numpy())

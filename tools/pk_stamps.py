@@ -1,0 +1,34 @@
+"""Where a step of the persistent decoder loop spends its cycles (diagnostic build: make -C csrc stamps, run with
+LAS_HIP_LIB=liblas_hip_stamps.so).  Prints, per role, the mean over workgroups of each phase's cycles per step."""
+import importlib, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from test_decoder_gpu import rand_weights
+ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+dec = importlib.import_module('end-to-end-asr-pytorch_amd.decoder')
+B, Tp, E, A, C, V, L = 24, 300, 640, 300, 320, 31, int(os.environ.get('L', 150))
+rng = np.random.RandomState(0)
+W = {k: torch.tensor(v, device='cuda') for k, v in rand_weights(rng, V, C, E, A, 1, True).items()}
+lens = sorted(rng.randint(180, Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+enc = torch.tanh(torch.randn(B, Tp, E, device='cuda')); psi = torch.tanh(torch.randn(B, Tp, A, device='cuda'))
+y = torch.randint(2, V, (B, L + 2), device='cuda'); y[:, 0] = 0
+lens_t = torch.tensor(lens, dtype=torch.int32, device='cuda')
+for it in range(3):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    S = dec.decoder_forward_raw(W, enc, psi, lens_t, y, L, 1, True)
+    e1.record(); torch.cuda.synchronize()
+print('forward %.3f ms = %.2f us/step' % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / L), 'status', int(S['pk_status'].item()))
+sync_bytes = (1 + 4 + 4 + 32 + 32) * 256
+dbg = S['pk_ws'][sync_bytes:sync_bytes + 256 * 12 * 8].view(torch.int64).view(256, 12).cpu().numpy().astype(np.float64) / L
+rows = dbg[dbg.sum(1) > 0]
+ncell = int(os.environ.get('NCELL', 80))
+names_c = ['q tile+signal', 'h-part mma', 'WAIT ctx', 'pull ctx+mma', 'pointwise+publish h', 'saved stores', 'WAIT h', 'pull h']
+names_a = ['conv', 'u', 'WAIT q', 'q+energies+publish', 's stores', 'WAIT e', 'softmax', 'ctx+publish', 'saved stores']
+for nm, r, names in (('cell', rows[:ncell], names_c), ('att', rows[ncell:], names_a)):
+    print(nm, 'workgroups', len(r), 'cycles/step total %.0f' % r.sum(1).mean())
+    for i, n in enumerate(names):
+        print('   %-22s mean %7.0f  min %7.0f  max %7.0f' % (n, r[:, i].mean(), r[:, i].min(), r[:, i].max()))

@@ -158,7 +158,8 @@ def main():
     dev = t.device
     # pre-stage distinct batches (per-step seed = 1234 + global batch index; each rank its own shard): in HBM for the
     # timed region behind `value`, and in pinned host memory for the H2D-inclusive loop
-    n_stage = min(8, a.steps + a.warmup)
+    # (no more distinct batches than warm-up steps: every staged shape has been through the allocator before the timed region)
+    n_stage = max(1, min(8, a.warmup, a.steps + a.warmup))
     staged, pinned = [], []
     for i in range(n_stage):
         x, y, lens = synth.make_batch(i * world + rank, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr, ctc=w['ctc'] > 0)

@@ -9,6 +9,7 @@
 // Sums over the L steps that are plain contractions (dW of every Linear/LSTMCell, d enc, d psi in dot mode)
 // are left to ONE las_gemm each after the loop, on the buffers this call fills.
 #include "las_mma.h"
+#include "decoder_pk.h"
 #include <stdlib.h>
 
 int las_skinny_launch(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
@@ -495,6 +496,7 @@ int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 
 extern "C" int64_t las_decoder_loc_acc_floats(int A) { return ((A * LOC_C + A + 1 + 3) / 4) * 4 + LOC_C * LOC_W; }
 extern "C" int las_decoder_att_chunks(int Tp) { return att_chunks(Tp); }
+extern "C" size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* d) { return las_dec_pk_bwd_ws_bytes(d); }
 
 static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                            const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
@@ -538,7 +540,13 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
     const bool fuse_pw = NL == 1;
     const bool drop = d->dropout > 0.f;
-    for (int t = L - 1; t >= 0; --t) {
+    // one persistent launch for the whole sequential chain when the shape / mode allows it and the caller gave the workspace
+    const bool pk = w.pk_ws && w.pk_status && las_dec_pk_bwd_ws_bytes(d) > 0;
+    if (pk) {
+        int rc = las_dec_pk_bwd(d, p, enc, enc_len, st_, g_htop, bw_, st);
+        if (rc) return rc;
+    }
+    for (int t = L - 1; t >= 0 && !pk; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
             const float* dh_ext = (l == NL - 1) ? g_htop + (long)t * BC : w.d_below;

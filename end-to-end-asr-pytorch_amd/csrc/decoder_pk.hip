@@ -22,7 +22,7 @@
 //
 // Hand-offs per step: ctx -> cell, h all-gather (cell), q -> attention, e all-gather (attention).  Spins are bounded; a
 // timeout sets *status = LAS_E_TIMEOUT and every workgroup exits.
-#include "las_mma.h"
+#include "pk_common.h"
 #include "decoder_pk.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -36,12 +36,7 @@ namespace {
 constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;     // reference asr.py:395-398
 constexpr int LWP = 208, NSEG = 4, SEGW = LWP / NSEG;              // taps padded with zeros, walked in 4 segments of 52
 constexpr float ATT_SCALE = 2.0f;                                 // reference asr.py:410
-constexpr int PNT = 512, PNW = PNT / 64;
-constexpr unsigned PK_SPIN = 1u << 22;
 constexpr int MAXB = 32, MAXNS = 4;
-constexpr int CLW = 64;                                           // words per counter line: every counter on its own 256 bytes
-constexpr size_t PK_MIN_LDS = 84 * 1024;                          // > 80 KiB: one workgroup per CU
-constexpr size_t PK_LDS_CAP = 160 * 1024;
 
 struct PkSync {                         // zeroed before every launch
     unsigned abort_[CLW];
@@ -73,98 +68,6 @@ struct PkArgs {
     PkSync* sync; int* status;
     unsigned long long* dbg;            // [grid][12] cycle sums per phase (stamps build only)
 };
-
-// ---- in-kernel cycle stamps (diagnostic build only: make stamps -> liblas_hip_stamps.so; the product build has none) ----
-#ifdef LAS_PK_STAMPS
-#define PK_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime()
-#define PK_STAMP(i)                                                          \
-    do {                                                                     \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
-        st_acc[i] += now_ - st_last;                                         \
-        st_last = now_;                                                      \
-    } while (0)
-#define PK_STAMP_FLUSH(dbg)                                                                          \
-    do {                                                                                             \
-        if (threadIdx.x == 0 && (dbg))                                                               \
-            for (int i_ = 0; i_ < 12; ++i_) (dbg)[(long)blockIdx.x * 12 + i_] = st_acc[i_];          \
-    } while (0)
-#else
-#define PK_STAMP_DECL
-#define PK_STAMP(i)
-#define PK_STAMP_FLUSH(dbg)
-#endif
-
-// ---- hand-off primitives ------------------------------------------------------------------------------------------
-// The LAST wave polls: lane l < n watches counter cnt0 + l*stride (one 4-byte sc1 load per lane and poll).  Result through
-// the LDS word `flag` (callers alternate between two words so that a fast wave cannot overwrite one still being read).
-__device__ __forceinline__ bool pk_block_wait(unsigned* cnt0, int stride, int n, unsigned target, unsigned* abort_word, int* flag) {
-    if (threadIdx.x >= PNT - 64) {
-        const int lane = threadIdx.x & 63;
-        unsigned* p = cnt0 + (long)min(lane, n - 1) * stride;
-        unsigned spins = 0;
-        bool ok = true;
-        while (__builtin_amdgcn_ballot_w64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0) {
-                if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = false; break; }
-                if (spins > PK_SPIN) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
-            }
-        }
-        if (lane == 0) *flag = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return *flag != 0;
-}
-// Publish: every storing wave drains its stores, workgroup barrier, one lane adds to the counter.
-__device__ __forceinline__ void pk_signal(unsigned* cnt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == PNT - 64) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// exchange store of the pair (a, b) at consecutive columns, sc1 (write-through): 4 bytes (bf16) / 8 bytes (f32)
-__device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
-    __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_pair_sc1(float* p, float a, float b) {
-    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Pull rows x cols (16-byte vectors, sc1 = L1 bypass) of a published tile into LDS; every load of a thread is issued
-// before its first LDS write; out-of-range lanes read through the buffer descriptor's bounds check (0, no branch).
-template <typename T, int VEC, int UNR>
-__device__ __forceinline__ void pk_pull(const T* __restrict__ src, int rows, int cols, int src_ld, T* __restrict__ lds, int ld) {
-    const int vpr = cols / VEC, total = rows * vpr;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows * src_ld * (int)sizeof(T), 0x00020000);
-    for (int i0 = threadIdx.x; i0 < total; i0 += PNT * UNR) {
-        u32x4 v[UNR];
-        int dst[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int i = i0 + u * PNT;
-            const int r = i / vpr, c = (i - r * vpr) * VEC;
-            dst[u] = i < total ? r * ld + c : -1;
-            const int off = i < total ? (r * src_ld + c) * (int)sizeof(T) : 0x7ffffff0;
-            v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (dst[u] >= 0) *(u32x4*)(lds + dst[u]) = v[u];
-    }
-}
-
-// four consecutive LDS values as floats: one 8-byte (bf16) / 16-byte (f32) read
-__device__ __forceinline__ float4 ld4(const bf16_t* p) {
-    const uint2 v = *(const uint2*)p;
-    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                       __uint_as_float(v.y & 0xffff0000u));
-}
-__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 
 // ---- cell role ---------------------------------------------------------------------------------------------------
 // LDS: Wl [4U][ld] rows flat = gate*U + unit, columns [0,Cp) = W_hh row, [Cp,Cp+Ep) = W_ih row (context part);
@@ -624,7 +527,7 @@ WsLayout ws_layout(const las_dec_dims* d, const PkGeom& g) {
     WsLayout w;
     size_t o = 0;
     w.sync = o; o += las_align(sizeof(PkSync));
-    w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 12);      // (read by tools/pk_stamps.py in the stamps build)
+    w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 20);      // (read by tools/pk_stamps.py in the stamps build)
     w.hx = o; o += las_align((size_t)2 * d->B * g.Cx * sz);
     w.cx = o; o += las_align((size_t)2 * d->B * g.Ex * sz);
     w.ebuf = o; o += las_align(sizeof(float) * 2 * d->B * d->Tp);

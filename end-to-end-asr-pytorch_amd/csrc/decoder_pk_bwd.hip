@@ -1,0 +1,692 @@
+// Persistent attend-and-spell decoder loop, backward through time: ONE launch for all L steps (location-aware attention,
+// one Speller layer, no dropout) instead of three launches per step.  Hand-written counterpart of what autograd derives
+// for reference src/asr.py:84-107; fills the same las_dec_bwd_state buffers as decoder_bwd.hip's per-step kernels
+// (dgates, dxin's context half, dq_pre, de, df), so the post-loop contractions (att_loc_post, att_conv_wgrad, the weight
+// gradient GEMMs) run unchanged.
+//
+// Per step t (newest first), with the hand-off protocol of pk_common.h between two roles:
+//   CELL workgroup (U hidden units, batch slice bs): cell pointwise backward -> its [Bs x 4U] slice of dgates_t; K-SPLIT
+//     product of that slice with its 4U rows of [W_ih(ctx part) | W_hh] -> a partial [Bs x (E + C)] of d ctx_t and of the
+//     recurrent d h_{t-1}, published as "pieces" (a reduce-scatter, as in the persistent LSTM's BPTT: nothing has to be
+//     gathered before the MFMAs).  d h_{t-1} = sum of the pieces addressed to it + d q_pre_t W_phi (its own 16 columns).
+//   ATTENTION workgroup (utterance b, part c): enc[b][all T'][E-slice] in LDS as in the forward loop.
+//     d ctx[E-slice] = sum of the cell pieces;  d a_part[t'] = enc[t'][slice] . d ctx[slice]  (+ for its own T'-chunk the
+//     location-conv path: the transposed conv of the NEXT step's d f) -> all-gather over the utterance's parts ->
+//     d a, the softmax dot, d e for its T'-chunk -> d z = d e w_e (1 - s^2), d q partial, d u = d z (1 - u^2),
+//     d f = d u W_lp (MFMA) -> published for the previous step's conv path; d q partials all-gathered, each part
+//     reduces an a-slice, applies (1 - q^2) and publishes d q_pre to the cell role.
+// Hand-offs on the chain per step: pieces (cell -> attention), d a parts, d q partials, d q_pre (attention -> cell).
+#include "pk_common.h"
+#include "decoder_pk.h"
+#include <stdlib.h>
+#include <stdio.h>
+
+extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
+                        int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta, float* C, int64_t ldc,
+                        int64_t strideC, const float* bias, int act, int batch, void* stream);
+
+namespace {
+
+constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;
+constexpr int LWP = 208, NSEG = 4, SEGW = LWP / NSEG;
+constexpr float ATT_SCALE = 2.0f;
+constexpr int MAXB = 32, MAXNS = 4;
+
+struct PbSync {                         // zeroed before every launch
+    unsigned abort_[CLW];
+    unsigned cnt_p[MAXNS][CLW];         // per batch slice: piece sets published (NCT per step)
+    unsigned cnt_da[MAXB][CLW];         // per utterance: d a parts published (NCH per step)
+    unsigned cnt_dqp[MAXB][CLW];        // per utterance: d q partials published
+    unsigned cnt_df[MAXB][CLW];         // per utterance: d f chunks published
+    unsigned cnt_dq[MAXB][CLW];         // per utterance: d q_pre slices published
+};
+
+struct PbGeom {
+    int U, NCT, NS, Bs, NB, NCELL;
+    int NCH, TC, ES, MT, NTW;
+    int NX;                             // piece row: [0,E) d ctx, [E,E+C) d h; padded to 16
+    int Ap;                             // A padded to the MFMA k-step
+    int AS;                             // d q_pre columns reduced per attention part
+    size_t lds;
+};
+
+struct PbArgs {
+    int B, Tp, E, A, C, L;
+    PbGeom g;
+    const float* enc; const int32_t* lens;
+    const float* w_ih; const float* w_hh; const float* w_phi; const float* conv_w; const float* w_lp; const float* w_e;
+    // saved by the forward loop
+    const float* att; const float* q; const float* gates; const float* cs; const float* f; const float* s;
+    const float* g_htop;
+    // outputs (las_dec_bwd_state)
+    float* dgates; float* dxin; float* dq_pre; float* de; float* df;
+    // exchange rings (2 slots each)
+    void* px;                           // [2][NCT][B][NX] compute type: K-split pieces
+    float* dax;                         // [2][B][NCH][Tp]
+    float* dqx;                         // [2][B][NCH][Ap]
+    float* dfx;                         // [2][B][10][Tp]
+    void* dqq;                          // [2][B][Ap] compute type: d q_pre
+    PbSync* sync; int* status;
+    unsigned long long* dbg;
+};
+
+// four consecutive values of the compute type as one store
+__device__ __forceinline__ void st4_sc1(bf16_t* p, float a, float b, float c, float d) {
+    const unsigned long long v = (unsigned long long)pack_bf16x2(a, b) | ((unsigned long long)pack_bf16x2(c, d) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st4_sc1(float* p, float a, float b, float c, float d) {
+    st_pair_sc1(p, a, b);
+    st_pair_sc1(p + 2, c, d);
+}
+__device__ __forceinline__ float ldb_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ float ct2f(float v) { return v; }
+__device__ __forceinline__ float ct2f(bf16_t v) { return bf2f(v); }
+
+// ---- cell role ---------------------------------------------------------------------------------------------------
+template <int PREC, int NB>
+__device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP;
+    const PbGeom& g = a.g;
+    const int j = blockIdx.x / g.NS, bs = blockIdx.x - j * g.NS;
+    const int U = g.U, j0 = j * U, b0 = bs * g.Bs, Bl = min(g.Bs, a.B - b0);
+    const int B = a.B, C = a.C, E = a.E, A = a.A, XI = C + E, NX = g.NX, Ap = g.Ap;
+    const int K4 = 4 * U, ldk = K4 + VEC, ldq = Ap + VEC, NKS = K4 / KSTEP, NTN = NX / 16;
+    T* WT = (T*)smem;                                   // [NX][ldk]   rows n: [0,E) W_ih[my rows][C + n], [E,E+C) W_hh[my rows][n - E]; k = gate*U + unit
+    T* Dl = WT + (size_t)NX * ldk;                      // [NB*16][ldk] my d gates of this step
+    T* WqT = Dl + NB * 16 * ldk;                        // [16][ldq]   W_phi[a][j0 + u] as rows u, k = a
+    T* Ql = WqT + 16 * ldq;                             // [NB*16][ldq] d q_pre rows of my batch slice
+    T* Pl = Ql + NB * 16 * ldq;                         // [NCT][NB*16][U] pieces addressed to me
+    float* Gl = (float*)(Pl + (size_t)g.NCT * NB * 16 * U);      // [PNW][NB*16][17]
+    int* flag = (int*)(Gl + PNW * NB * 16 * 17);
+
+    for (int i = threadIdx.x; i < NX * ldk; i += PNT) {
+        const int k = i % ldk, n = i / ldk, gi = k / U, u = k - gi * U;
+        float v = 0.f;
+        if (k < K4 && j0 + u < C) {
+            const long wr = (long)gi * C + j0 + u;
+            if (n < E) v = a.w_ih[wr * XI + C + n];
+            else if (n - E < C) v = a.w_hh[wr * C + (n - E)];
+        }
+        WT[i] = to_ct<T>(v);
+    }
+    for (int i = threadIdx.x; i < NB * 16 * ldk; i += PNT) Dl[i] = (T)0;
+    for (int i = threadIdx.x; i < 16 * ldq; i += PNT) {
+        const int k = i % ldq, u = i / ldq;
+        WqT[i] = to_ct<T>((u < U && j0 + u < C && k < A) ? a.w_phi[(long)k * C + j0 + u] : 0.f);
+    }
+    for (int i = threadIdx.x; i < NB * 16 * ldq; i += PNT) Ql[i] = (T)0;
+    __syncthreads();
+
+    const int er = threadIdx.x / U, en = threadIdx.x - er * U, ej = j0 + en;
+    const bool ev = er < Bl && ej < C && threadIdx.x < NB * 16 * U;
+    float dc_carry = 0.f;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+    unsigned* abort_word = a.sync->abort_;
+    unsigned nwait = 0;
+    T* px = (T*)a.px;
+    T* dqq = (T*)a.dqq;
+    PK_STAMP_DECL;
+
+    for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
+        // saved activations of my element
+        float gi_ = 0.f, gf_ = 0.f, gg_ = 0.f, go_ = 0.f, ct = 0.f, cp = 0.f, dh = 0.f;
+        if (ev) {
+            const long ro = (long)t * B + b0 + er;
+            const float* gp = a.gates + ro * 4 * C;
+            gi_ = gp[ej]; gf_ = gp[C + ej]; gg_ = gp[2 * C + ej]; go_ = gp[3 * C + ej];
+            ct = a.cs[(ro + B) * C + ej]; cp = a.cs[ro * C + ej];
+            dh = a.g_htop[ro * C + ej];
+        }
+        PK_STAMP(0);
+        if (t + 1 < a.L) {
+            // ---- recurrent d h_t = sum of the pieces of step t+1 addressed to my units + d q_pre_{t+1} W_phi
+            if (!pk_block_wait(&a.sync->cnt_p[bs][0], 0, 1, (unsigned)g.NCT * (n - 1), abort_word, flag + (nwait++ & 1))) {
+                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                return;
+            }
+            {
+                const int vpr = U / VEC > 0 ? U / VEC : 1;          // 16-byte vectors per (producer, row)
+                const T* src = px + ((size_t)((t + 1) & 1) * g.NCT * B) * NX;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.NCT * B * NX * (int)sizeof(T), 0x00020000);
+                for (int i = threadIdx.x; i < g.NCT * Bl * vpr; i += PNT) {
+                    const int pj = i / (Bl * vpr), rem = i - pj * (Bl * vpr), r = rem / vpr, v = rem - r * vpr;
+                    const int off = (((pj * B) + b0 + r) * NX + E + j0 + v * VEC) * (int)sizeof(T);
+                    const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+                    *(u32x4*)(Pl + ((size_t)pj * NB * 16 + r) * U + v * VEC) = val;
+                }
+            }
+            PK_STAMP(1);
+            if (!pk_block_wait(&a.sync->cnt_dq[b0][0], CLW, Bl, (unsigned)g.NCH * (n - 1), abort_word, flag + (nwait++ & 1))) {
+                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                return;
+            }
+            PK_STAMP(2);
+            pk_pull<T, VEC, 2>(dqq + ((size_t)((t + 1) & 1) * B + b0) * Ap, Bl, Ap, Ap, Ql, ldq);
+            __syncthreads();
+            f32x4 qa[NB];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) qa[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ks = wave; ks < Ap / KSTEP; ks += PNW) mma_rows<PREC, NB>(qa, Ql + ks * KSTEP, ldq, WqT + ks * KSTEP, ldq, 1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Gl[(wave * NB * 16 + bt * 16 + fq * 4 + r) * 17 + fr] = qa[bt][r];
+            __syncthreads();
+            if (ev) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < PNW; ++w) v += Gl[(w * NB * 16 + er) * 17 + en];
+                for (int pj = 0; pj < g.NCT; ++pj) v += ct2f(Pl[((size_t)pj * NB * 16 + er) * U + en]);
+                dh += v;
+            }
+            PK_STAMP(3);
+        }
+        // ---- cell pointwise backward (reference asr.py:353 LSTMCell, gate order i,f,g,o)
+        float dg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ev) {
+            const float tc = fast_tanh(ct);
+            const float dc = dh * go_ * (1.f - tc * tc) + dc_carry;
+            dg[0] = dc * gg_ * gi_ * (1.f - gi_);
+            dg[1] = dc * cp * gf_ * (1.f - gf_);
+            dg[2] = dc * gi_ * (1.f - gg_ * gg_);
+            dg[3] = dh * tc * go_ * (1.f - go_);
+            dc_carry = dc * gf_;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) Dl[er * ldk + gi * U + en] = to_ct<T>(dg[gi]);
+        }
+        __syncthreads();
+        // ---- K-split product: my d gates slice x my rows of [W_ih(ctx) | W_hh], transposed so that a lane ends up with 4
+        // consecutive output columns of one batch row (one 8-byte store per tile)
+        {
+            T* dst = px + ((size_t)(t & 1) * g.NCT + j) * B * NX;
+            for (int tile = wave; tile < NTN; tile += PNW) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+                    mma_rows<PREC, 1>(acc, WT + (size_t)tile * 16 * ldk, ldk, Dl + bt * 16 * ldk, ldk, NKS);
+                    const int row = bt * 16 + fr;
+                    if (row < Bl) st4_sc1(dst + (size_t)(b0 + row) * NX + tile * 16 + fq * 4, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                }
+            }
+        }
+        pk_signal(&a.sync->cnt_p[bs][0]);
+        PK_STAMP(4);
+        if (ev) {
+            float* go = a.dgates + ((long)t * B + b0 + er) * 4 * C;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) __builtin_nontemporal_store(dg[gi], &go[gi * C + ej]);
+        }
+        PK_STAMP(5);
+    }
+    PK_STAMP_FLUSH(a.dbg);
+}
+
+// ---- attention role ----------------------------------------------------------------------------------------------
+template <int PREC, int MT, int NTW>
+__device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
+    typedef typename CT<PREC>::T T;
+    constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
+    const PbGeom& g = a.g;
+    const int id = blockIdx.x - g.NCELL, b = id / g.NCH, c = id - b * g.NCH;
+    const int bs = b / g.Bs;
+    const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E, Ap = g.Ap, NX = g.NX;
+    const int len = a.lens[b];
+    const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0)), tcv = max(0, min(TCr, len - r0));
+    const int ES = g.ES, e0 = c * ES, ESr = max(0, min(ES, E - e0)), ESp = ES + 4;
+    const int TCq = (TC + 3) / 4, Tp4 = (Tp + 3) & ~3, lda_ = Ap + VEC;
+    const int a0 = c * g.AS, ASr = max(0, min(g.AS, A - a0));          // my d q_pre columns
+    // d f window of the conv path: frames r0 - K .. r0 + TC + K; an ODD number of 16-byte vectors per channel row, so that the
+    // ten channels' windows do not sit on the same LDS banks (with 256-float rows the conv's reads were 6-way conflicts)
+    const int WN = (4 * TCq + 2 * LOC_K + 12) + (((4 * TCq + 2 * LOC_K + 12) / 4) % 2 == 0 ? 4 : 0);
+    // LDS (every float array 16-byte aligned)
+    T* enc_l = (T*)smem;                                         // [Tp][ESp]
+    float* cwf_l = (float*)(smem + (((size_t)Tp * ESp * sizeof(T) + 15) & ~(size_t)15));      // [10][LWP] FLIPPED taps, zero padded
+    float* att_l = cwf_l + LOC_C * LWP;                          // [Tp4]
+    float* da_l = att_l + Tp4;                                   // [Tp4]
+    float* dctx_l = da_l + Tp4;                                  // [ES]
+    float* de_l = dctx_l + ES;                                   // [MT*16]
+    float* ct_l = de_l + MT * 16;                                // [MT*16] conv-path term of my frames
+    float* dqp_l = ct_l + MT * 16;                               // [4][NTW*128] d q partials per lane row group
+    float* dfa_l = dqp_l + 4 * NTW * PNW * 16;                   // [MT*16][16] d f accumulators (LDS float adds)
+    float* red = dfa_l + MT * 16 * 16;                           // [64]
+    int* flag = (int*)(red + 64);                                // [4]
+    T* Wt = (T*)(flag + 4);                                      // [NTW*128][LDK] W_lp rows (a x channels) for u = tanh(W_lp f)
+    T* WlT = Wt + NTW * PNW * 16 * LDK;                          // [16][lda_] W_lp^T rows (channel x a) for d f = d u W_lp
+    T* Ft = WlT + 16 * lda_;                                     // [MT*16][LDK] f of my frames
+    char* scratch = (char*)(Ft + MT * 16 * LDK);                 // phase A: d f window + conv partials; phase E: d u tile
+    float* dfn_l = (float*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);       // [10][WN]
+    float* f4_l = dfn_l + LOC_C * WN;                            // [NSEG][10][TCq][4]
+    T* Du = (T*)dfn_l;                                           // [MT*16][lda_]   (aliases the two above)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+
+    // ---- prologue
+    for (int i = threadIdx.x; i < Tp * ESp; i += PNT) {
+        const int tp = i / ESp, col = i - tp * ESp;
+        enc_l[i] = to_ct<T>((col < ESr && tp < len) ? a.enc[((long)b * Tp + tp) * E + e0 + col] : 0.f);
+    }
+    for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
+        const int k = i % LDK, aa = i / LDK;
+        Wt[i] = to_ct<T>((k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+    }
+    for (int i = threadIdx.x; i < 16 * lda_; i += PNT) {
+        const int k = i % lda_, cc = i / lda_;
+        WlT[i] = to_ct<T>((cc < LOC_C && k < A) ? a.w_lp[(long)k * LOC_C + cc] : 0.f);
+    }
+    for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
+    for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) {
+        const int cc = i / LWP, k = i - cc * LWP;                                // flipped: w'[c][k'] = w[c][2K - k']
+        cwf_l[i] = k < LOC_W ? a.conv_w[cc * LOC_W + (LOC_W - 1 - k)] : 0.f;
+    }
+    for (int i = threadIdx.x; i < MT * 16; i += PNT) ct_l[i] = 0.f;
+    __syncthreads();
+    float wev[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? a.w_e[aa] : 0.f; }
+    unsigned* abort_word = a.sync->abort_;
+    unsigned nwait = 0;
+    T* px = (T*)a.px;
+    T* dqq = (T*)a.dqq;
+    const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
+              cv_qd = threadIdx.x - cv_sg * (LOC_C * TCq) - cv_cc * TCq;
+    // window origin: dfn_l[cc][x] = d f_next[cc][r0 - LOC_K - sh + x], sh chosen so that frame r0's window start is 16-byte aligned
+    float sv[MT][NTW][4];
+    auto load_s = [&](int t_) {                                  // saved s of step t_ for my elements (clamped addresses)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tp = min(r0 + mt * 16 + fq * 4 + r, Tp - 1);
+                const float* __restrict__ sp = a.s + (((long)t_ * B + b) * Tp + tp) * A;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) sv[mt][j][r] = sp[min((wave + PNW * j) * 16 + fr, A - 1)];
+            }
+    };
+    PK_STAMP_DECL;
+
+    for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
+        // ---- (A) everything that needs no d ctx_t: attention, u = tanh(W_lp f_t), the conv path of d f_{t+1}
+        for (int i = threadIdx.x; i < Tp; i += PNT) att_l[i] = a.att[((long)(t + 1) * B + b) * Tp + i];
+        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+            const int cc = i / TC, tt = i - cc * TC;
+            Ft[tt * LDK + cc] = to_ct<T>(tt < TCr ? a.f[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt] : 0.f);
+        }
+        const float qq_f = a.q[((long)t * B + b) * A + min(a0 + (int)threadIdx.x, A - 1)];      // (for phase F)
+        PK_STAMP(9);
+        if (t + 1 < a.L) {
+            // d f_{t+1} of the frames around my chunk (published by my utterance's parts at the end of step t+1)
+            if (!pk_block_wait(&a.sync->cnt_df[b][0], 0, 1, (unsigned)g.NCH * (n - 1), abort_word, flag + (nwait++ & 1))) {
+                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                return;
+            }
+            // (16-byte loads: chunks start on multiples of 4 frames and the exchange rows have stride Tp4; frames beyond T' are
+            // never written and read as the zeros of the initial memset, frames < 0 are whole vectors)
+            {
+                const float* src = a.dfx + ((size_t)((t + 1) & 1) * B + b) * LOC_C * Tp4;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, LOC_C * Tp4 * 4, 0x00020000);
+                const int wq = WN / 4;
+                for (int i = threadIdx.x; i < LOC_C * wq; i += PNT) {
+                    const int cc = i / wq, x4 = i - cc * wq, tp = r0 - LOC_K + 4 * x4;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (tp >= 0 && tp < Tp4) v = __builtin_amdgcn_raw_buffer_load_b128(rs, (cc * Tp4 + tp) * 4, 0, 16);
+                    *(u32x4*)(dfn_l + cc * WN + 4 * x4) = v;
+                }
+            }
+            __syncthreads();
+            PK_STAMP(10);
+            // conv path: ct[t'] = sum_c sum_k' w'[c][k'] d f_{t+1}[c][t' + k' - K]   (the forward conv's form, flipped taps)
+            for (int i = threadIdx.x; i < NSEG * LOC_C * TCq; i += PNT) {
+                int sg = cv_sg, cc = cv_cc, qd = cv_qd;
+                if (i >= PNT) { sg = i / (LOC_C * TCq); const int rem = i - sg * (LOC_C * TCq); cc = rem / TCq; qd = rem - cc * TCq; }
+                if (4 * qd >= TCr) { *(float4*)(f4_l + (size_t)i * 4) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+                const float* w = cwf_l + cc * LWP + sg * SEGW;
+                const float* p = dfn_l + cc * WN + 4 * qd + sg * SEGW;
+                float4 lo = *(const float4*)p;
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 4
+                for (int k = 0; k < SEGW; k += 4) {
+                    const float4 wv = *(const float4*)(w + k), hi = *(const float4*)(p + k + 4);
+                    o0 = fmaf(wv.x, lo.x, fmaf(wv.y, lo.y, fmaf(wv.z, lo.z, fmaf(wv.w, lo.w, o0))));
+                    o1 = fmaf(wv.x, lo.y, fmaf(wv.y, lo.z, fmaf(wv.z, lo.w, fmaf(wv.w, hi.x, o1))));
+                    o2 = fmaf(wv.x, lo.z, fmaf(wv.y, lo.w, fmaf(wv.z, hi.x, fmaf(wv.w, hi.y, o2))));
+                    o3 = fmaf(wv.x, lo.w, fmaf(wv.y, hi.x, fmaf(wv.z, hi.y, fmaf(wv.w, hi.z, o3))));
+                    lo = hi;
+                }
+                *(float4*)(f4_l + (size_t)i * 4) = make_float4(o0, o1, o2, o3);
+            }
+            __syncthreads();
+            float cpart = 0.f;
+            if (threadIdx.x < 4 * TC) {                       // thread = (frame, tap segment): its 10 channel partials
+                const int tt = threadIdx.x >> 2, sg = threadIdx.x & 3;
+#pragma unroll
+                for (int cc = 0; cc < LOC_C; ++cc) cpart += f4_l[(((size_t)sg * LOC_C + cc) * TCq + (tt >> 2)) * 4 + (tt & 3)];
+            }
+            cpart += las_dpp<0x111, 0xf>(0.f, cpart);        // + lane - 1, + lane - 2: lane 4 tt + 3 ends with the frame's total
+            cpart += las_dpp<0x112, 0xf>(0.f, cpart);
+            if (threadIdx.x < 4 * TC && (threadIdx.x & 3) == 3) ct_l[threadIdx.x >> 2] = cpart;
+        }
+        __syncthreads();
+        load_s(t);                      // in flight during the u recompute and the wait for the pieces; first used in phase E
+        PK_STAMP(0);
+        // 1 - u^2 of my elements (u = tanh(F W_lp^T) on the MFMA), kept in registers
+        float um[MT][NTW][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+                mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = fast_tanh(acc[0][r]);
+                    um[mt][j][r] = 1.f - u * u;
+                    asm volatile("" : "+v"(um[mt][j][r]));
+                }
+            }
+        PK_STAMP(1);
+        // ---- (B) d ctx of my E-slice: sum of the cell role's pieces of this step
+        if (!pk_block_wait(&a.sync->cnt_p[bs][0], 0, 1, (unsigned)g.NCT * n, abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(2);
+        {
+            // one 16-byte sc1 load per (producer, column vector) -> psum_l[producer][ES] (fp32, in the scratch region, free
+            // between the conv path and the d u tile); then thread (column, quarter of the producers), then 4 partials.
+            // (LDS float atomics instead: 12 900 cycles -- they retire about one LANE per 3 cycles, cycle stamps)
+            float* psum_l = dfn_l;                                           // [NCT][ES]
+            const int nv = ES / VEC;
+            const T* src = px + (size_t)(t & 1) * g.NCT * B * NX;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.NCT * B * NX * (int)sizeof(T), 0x00020000);
+            for (int i = threadIdx.x; i < g.NCT * nv; i += PNT) {
+                const int pj = i / nv, v = i - pj * nv, col = e0 + v * VEC;
+                u32x4 raw = {0u, 0u, 0u, 0u};
+                if (col < E) raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (((pj * B + b) * NX) + col) * (int)sizeof(T), 0, 16);
+                float* o = psum_l + pj * ES + v * VEC;
+                if constexpr (PREC == LAS_PREC_BF16) {
+                    *(float4*)o = make_float4(__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
+                                              __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u));
+                    *(float4*)(o + 4) = make_float4(__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u),
+                                                    __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u));
+                } else {
+                    *(u32x4*)o = raw;
+                }
+            }
+            __syncthreads();
+            float part4 = 0.f;
+            if (threadIdx.x < 4 * ES) {
+                const int e = threadIdx.x >> 2, qd = threadIdx.x & 3;
+                for (int pj = qd; pj < g.NCT; pj += 4) part4 += psum_l[pj * ES + e];
+            }
+            part4 += las_dpp<0x111, 0xf>(0.f, part4);
+            part4 += las_dpp<0x112, 0xf>(0.f, part4);
+            if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) dctx_l[threadIdx.x >> 2] = part4;
+        }
+        __syncthreads();
+        PK_STAMP(11);
+        // ---- (C) d a over my E-slice for every frame of the utterance (+ the conv path for my own frames)
+        for (int tp = threadIdx.x; tp < len; tp += PNT) {
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            const T* er_ = enc_l + (size_t)tp * ESp;
+            for (int e = 0; e < ES; e += 4) {
+                const float4 v = ld4(er_ + e), d = *(const float4*)(dctx_l + e);
+                c0 = fmaf(v.x, d.x, c0); c1 = fmaf(v.y, d.y, c1); c2 = fmaf(v.z, d.z, c2); c3 = fmaf(v.w, d.w, c3);
+            }
+            float v = (c0 + c1) + (c2 + c3);
+            if (tp >= r0 && tp < r0 + TCr) v += ct_l[tp - r0];
+            st_sc1(a.dax + (((size_t)(t & 1) * B + b) * g.NCH + c) * Tp + tp, v);
+        }
+        PK_STAMP(12);
+        pk_signal(&a.sync->cnt_da[b][0]);
+        PK_STAMP(3);
+        if (threadIdx.x < ESr) a.dxin[((long)t * B + b) * XI + C + e0 + threadIdx.x] = dctx_l[threadIdx.x];
+        // ---- (D) all parts' d a: softmax backward for my frames
+        if (!pk_block_wait(&a.sync->cnt_da[b][0], 0, 1, (unsigned)g.NCH * n, abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(4);
+        float part = 0.f;
+        __amdgpu_buffer_rsrc_t rs_da = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dax + ((size_t)(t & 1) * B + b) * g.NCH * Tp), 0,
+                                                                         g.NCH * Tp * 4, 0x00020000);
+        for (int tp = threadIdx.x; tp < len; tp += PNT) {
+            float v = 0.f, pv_[16];
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) pv_[pc] = pc < g.NCH ? ldb_sc1(rs_da, (pc * Tp + tp) * 4) : 0.f;
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) v += pv_[pc];
+            da_l[tp] = v;
+            part = fmaf(att_l[tp], v, part);
+        }
+        const float dot = block_sum(part, red);              // (its barriers also publish da_l)
+        if (threadIdx.x < MT * 16) {
+            const int tt = threadIdx.x, tp = r0 + tt;
+            const float v = tt < tcv ? ATT_SCALE * att_l[tp] * (da_l[tp] - dot) : 0.f;
+            de_l[tt] = v;
+            if (tt < TCr) __builtin_nontemporal_store(v, &a.de[((long)t * B + b) * Tp + tp]);
+        }
+        __syncthreads();
+        PK_STAMP(5);
+        // ---- (E) energy backward: d z = d e w_e (1 - s^2); d q partial = sum over my frames; d u = d z (1 - u^2) -> LDS
+        float dq[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) dq[j] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tt = mt * 16 + fq * 4 + r;
+                const float de = de_l[tt];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const float s_ = sv[mt][j][r];
+                    const float dz = de * wev[j] * (1.f - s_ * s_);
+                    dq[j] += dz;
+                    const int aa = (wave + PNW * j) * 16 + fr;
+                    if (aa < Ap) Du[tt * lda_ + aa] = to_ct<T>(dz * um[mt][j][r]);
+                }
+            }
+        PK_STAMP(13);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) dqp_l[fq * (NTW * PNW * 16) + (wave + PNW * j) * 16 + fr] = dq[j];
+        __syncthreads();
+        for (int aa = threadIdx.x; aa < A; aa += PNT) {
+            const float v = (dqp_l[aa] + dqp_l[NTW * PNW * 16 + aa]) + (dqp_l[2 * NTW * PNW * 16 + aa] + dqp_l[3 * NTW * PNW * 16 + aa]);
+            st_sc1(a.dqx + (((size_t)(t & 1) * B + b) * g.NCH + c) * Ap + aa, v);
+        }
+        PK_STAMP(14);
+        // d f[c][t'] = sum_a d u[t'][a] W_lp[a][c]: MFMA over k = a, the waves split the k-steps, LDS float adds combine them
+        // (one wave per 16-frame tile walks all k-steps and keeps the sums in registers: with the k-steps split over the waves
+        // the LDS float adds that combined them cost 14 900 cycles a step, cycle stamps)
+        if (wave < MT) {
+            f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+            mma_rows<PREC, 1>(acc, Du + wave * 16 * lda_, lda_, WlT, lda_, Ap / KSTEP);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dfa_l[(wave * 16 + fq * 4 + r) * 16 + fr] = acc[0][r];
+        }
+        __syncthreads();
+        PK_STAMP(15);
+        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+            const int cc = i / TC, tt = i - cc * TC;
+            if (tt < TCr) st_sc1(a.dfx + (((size_t)(t & 1) * B + b) * LOC_C + cc) * Tp4 + r0 + tt, tt < tcv ? dfa_l[tt * 16 + cc] : 0.f);
+        }
+        PK_STAMP(16);
+        pk_signal(&a.sync->cnt_dqp[b][0]);
+        if (threadIdx.x == PNT - 64) __hip_atomic_fetch_add(&a.sync->cnt_df[b][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PK_STAMP(6);
+        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+            const int cc = i / TC, tt = i - cc * TC;
+            if (tt < tcv) __builtin_nontemporal_store(dfa_l[tt * 16 + cc], &a.df[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt]);
+        }
+        // ---- (F) d q_pre of my a-slice: sum of the parts' partials, times (1 - q^2); to the cell role
+        if (!pk_block_wait(&a.sync->cnt_dqp[b][0], 0, 1, (unsigned)g.NCH * n, abort_word, flag + (nwait++ & 1))) {
+            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+            return;
+        }
+        PK_STAMP(7);
+        {
+            const int k = threadIdx.x, aa = a0 + k;
+            float v = 0.f;
+            if (k < ASr) {
+                __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dqx + ((size_t)(t & 1) * B + b) * g.NCH * Ap), 0,
+                                                                                g.NCH * Ap * 4, 0x00020000);
+                const float qq = qq_f;
+                float pv_[16];
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) pv_[pc] = pc < g.NCH ? ldb_sc1(rs_q, (pc * Ap + aa) * 4) : 0.f;
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) v += pv_[pc];
+                v *= 1.f - qq * qq;
+            }
+            const float vnext = las_dpp<0x101, 0xf>(0.f, v);
+            if (k < ASr && !(k & 1)) st_pair_sc1(dqq + ((size_t)(t & 1) * B + b) * Ap + aa, v, k + 1 < ASr ? vnext : 0.f);
+            pk_signal(&a.sync->cnt_dq[b][0]);
+            if (k < ASr) a.dq_pre[((long)t * B + b) * A + aa] = v;
+        }
+        PK_STAMP(8);
+    }
+    PK_STAMP_FLUSH(a.dbg);
+}
+
+template <int PREC, int NB, int MT, int NTW>
+__global__ __launch_bounds__(PNT) void dec_pk_bwd_kernel(PbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < a.g.NCELL) pb_cell_role<PREC, NB>(a, smem);
+    else pb_att_role<PREC, MT, NTW>(a, smem);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+size_t pb_cell_lds(int prec, const PbGeom& g) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4;
+    return ((size_t)(g.NX + g.NB * 16) * (4 * g.U + vec) + (size_t)(16 + g.NB * 16) * (g.Ap + vec) + (size_t)g.NCT * g.NB * 16 * g.U) * sz +
+           sizeof(float) * PNW * g.NB * 16 * 17 + 64;
+}
+size_t pb_att_lds(int prec, const PbGeom& g, int Tp, int A) {
+    const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ldk = prec == LAS_PREC_BF16 ? 40 : 20;
+    const size_t Tp4 = (Tp + 3) & ~3, TCq = (g.TC + 3) / 4, WN = 4 * TCq + 2 * LOC_K + 16, lda_ = g.Ap + vec;
+    const size_t scratchA = sizeof(float) * (LOC_C * WN + NSEG * LOC_C * TCq * 4), scratchE = (size_t)g.MT * 16 * lda_ * sz;
+    return (size_t)Tp * (g.ES + 4) * sz + 16 +
+           sizeof(float) * (LOC_C * LWP + 2 * Tp4 + g.ES + 2 * g.MT * 16 + 4 * g.NTW * PNW * 16 + g.MT * 16 * 16 + 64 + 4) +
+           ((size_t)g.NTW * PNW * 16 * ldk + 16 * lda_ + (size_t)g.MT * 16 * ldk) * sz + 16 + (scratchA > scratchE ? scratchA : scratchE) + 64;
+}
+
+bool pb_geom(const las_dec_dims* d, PbGeom& best) {
+    if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
+    if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
+    if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
+    if (getenv("LAS_DEC_NO_PK") || getenv("LAS_DEC_NO_PK_BWD")) return false;
+    const int ks = d->prec == LAS_PREC_BF16 ? 32 : 16, vec = d->prec == LAS_PREC_BF16 ? 8 : 4;
+    int want_ns = 0, want_u = 0;
+    if (const char* e = getenv("LAS_DEC_PKB_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);      // (A/B measurements)
+    static const int cand[4][2] = {{2, 8}, {1, 8}, {2, 16}, {1, 16}};
+    for (int ci = 0; ci < 4; ++ci) {
+        PbGeom g{};
+        g.NS = cand[ci][0]; g.U = cand[ci][1];
+        if (want_ns && (g.NS != want_ns || g.U != want_u)) continue;
+        if (g.NS > 1 && d->B < 8) continue;
+        if ((4 * g.U) % ks) continue;                    // my d gates slice must be whole k-steps
+        g.Bs = (d->B + g.NS - 1) / g.NS;
+        g.NS = (d->B + g.Bs - 1) / g.Bs;
+        g.NB = g.Bs <= 16 ? 1 : 2;
+        if (g.Bs > 32) continue;
+        g.NCT = (d->C + g.U - 1) / g.U;
+        g.NCELL = g.NCT * g.NS;
+        g.NX = (d->E + d->C + 15) / 16 * 16;
+        g.Ap = (d->A + ks - 1) / ks * ks;
+        if ((g.U * (d->prec == LAS_PREC_BF16 ? 2 : 4)) % 16 || d->E % vec) continue;     // piece pulls are 16-byte vectors
+        if (pb_cell_lds(d->prec, g) > PK_LDS_CAP) continue;
+        g.NCH = (256 - g.NCELL) / d->B;
+        if (g.NCH > 16) g.NCH = 16;
+        if (g.NCH < 1) continue;
+        g.TC = ((d->Tp + g.NCH - 1) / g.NCH + 3) / 4 * 4;         // chunks start on multiples of 4 frames (16-byte window loads)
+        if (g.TC > 64) continue;
+        g.MT = g.TC <= 32 ? 2 : g.TC <= 48 ? 3 : 4;
+        g.NTW = d->A <= 128 ? 1 : d->A <= 384 ? 3 : 4;
+        if (g.NTW == 4 && g.MT == 4) continue;
+        g.ES = ((d->E + g.NCH - 1) / g.NCH + vec - 1) / vec * vec;
+        if (g.ES / 4 > PNT || g.ES > PNT) continue;
+        g.AS = ((d->A + g.NCH - 1) / g.NCH + 1) / 2 * 2;
+        if (g.AS > PNT) continue;
+        if (pb_att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
+        g.lds = pb_cell_lds(d->prec, g);
+        const size_t al = pb_att_lds(d->prec, g, d->Tp, d->A);
+        if (al > g.lds) g.lds = al;
+        if (g.lds < PK_MIN_LDS) g.lds = PK_MIN_LDS;
+        best = g;
+        return true;
+    }
+    return false;
+}
+
+struct PbWs { size_t sync, dbg, px, dax, dqx, dfx, dqq, total; };
+PbWs pb_ws(const las_dec_dims* d, const PbGeom& g) {
+    const size_t sz = d->prec == LAS_PREC_BF16 ? 2 : 4;
+    PbWs w;
+    size_t o = 0;
+    w.sync = o; o += las_align(sizeof(PbSync));
+    w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 20);
+    w.px = o; o += las_align((size_t)2 * g.NCT * d->B * g.NX * sz);
+    w.dax = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * d->Tp);
+    w.dqx = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * g.Ap);
+    w.dfx = o; o += las_align(sizeof(float) * 2 * d->B * LOC_C * ((d->Tp + 3) & ~3));
+    w.dqq = o; o += las_align((size_t)2 * d->B * g.Ap * sz);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+size_t las_dec_pk_bwd_ws_bytes(const las_dec_dims* d) {
+    PbGeom g;
+    if (!pb_geom(d, g)) return 0;
+    return pb_ws(d, g).total;
+}
+
+int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const int32_t* enc_len,
+                   const las_dec_state* st, const float* g_htop, las_dec_bwd_state* bw, hipStream_t stream) {
+    PbGeom g;
+    if (!pb_geom(d, g)) return LAS_E_UNSUPPORTED;
+    LAS_CHECK_ARG(bw->pk_ws && bw->pk_status && st->f && st->s && bw->df && bw->de && p->conv_w && p->w_lp && p->w_e);
+    const PbWs w = pb_ws(d, g);
+    char* ws = (char*)bw->pk_ws;
+    const int B = d->B, C = d->C, E = d->E, XI = C + E, L = d->L;
+    LAS_HIP(hipMemsetAsync(ws, 0, w.total, stream));
+    PbArgs a{};
+    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g;
+    a.enc = enc; a.lens = enc_len;
+    a.w_ih = p->w_ih[0]; a.w_hh = p->w_hh[0]; a.w_phi = p->w_phi; a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e;
+    a.att = st->att; a.q = st->q; a.gates = st->gates; a.cs = st->cs; a.f = st->f; a.s = st->s; a.g_htop = g_htop;
+    a.dgates = bw->dgates; a.dxin = bw->dxin; a.dq_pre = bw->dq_pre; a.de = bw->de; a.df = bw->df;
+    a.px = ws + w.px; a.dax = (float*)(ws + w.dax); a.dqx = (float*)(ws + w.dqx); a.dfx = (float*)(ws + w.dfx); a.dqq = ws + w.dqq;
+    a.sync = (PbSync*)(ws + w.sync); a.status = bw->pk_status; a.dbg = (unsigned long long*)(ws + w.dbg);
+    const int grid = g.NCELL + B * g.NCH;
+    int launched = 0;
+#define LAS_PB_GO(P_, N_, M_, W_)                                                                                  \
+    {                                                                                                             \
+        auto k = dec_pk_bwd_kernel<P_, N_, M_, W_>;                                                               \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PNT), g.lds, stream, a);                                           \
+        LAS_LAUNCH_OK();                                                                                          \
+        launched = 1;                                                                                             \
+    }
+#define LAS_PB_W(P_, N_, M_)                                                                                       \
+    {                                                                                                             \
+        if (g.NTW == 1) LAS_PB_GO(P_, N_, M_, 1) else if (g.NTW == 3) LAS_PB_GO(P_, N_, M_, 3) else LAS_PB_GO(P_, N_, M_, 4) \
+    }
+#define LAS_PB_M(P_, N_)                                                                                           \
+    {                                                                                                             \
+        if (g.MT == 2) LAS_PB_W(P_, N_, 2) else if (g.MT == 3) LAS_PB_W(P_, N_, 3) else LAS_PB_W(P_, N_, 4)        \
+    }
+    if (d->prec == LAS_PREC_BF16) { if (g.NB == 1) LAS_PB_M(LAS_PREC_BF16, 1) else LAS_PB_M(LAS_PREC_BF16, 2) }
+    else { if (g.NB == 1) LAS_PB_M(LAS_PREC_F32, 1) else LAS_PB_M(LAS_PREC_F32, 2) }
+#undef LAS_PB_M
+#undef LAS_PB_W
+#undef LAS_PB_GO
+    if (!launched) return LAS_E_BADARG;
+    // d xin's embedding half for every step: d gates [L*B x 4C] x W_ih[:, 0:C]   (off the sequential chain: one GEMM)
+    return las_gemm(d->prec, 0, 0, L * B, C, 4 * C, 1.f, bw->dgates, 4 * C, 0, p->w_ih[0], XI, 0, 0.f, bw->dxin, XI, 0, nullptr, 0, 1,
+                    (void*)stream);
+}

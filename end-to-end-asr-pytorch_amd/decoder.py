@@ -134,7 +134,7 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
 
 class DecBwdState(ctypes.Structure):
     _fields_ = [(n, P) for n in ('dgates', 'dxin', 'dq_pre', 'de', 'dh_carry', 'dc_carry', 'd_below', 'da', 'df',
-                                 'dpsi', 'acc', 'demb')]
+                                 'dpsi', 'acc', 'demb', 'pk_ws', 'pk_status')]
 
 
 def transpose2d(w):
@@ -164,6 +164,8 @@ class DecoderFn(torch.autograd.Function):
     forward(enc [B,T',E], psi [B,T',A], enc_len i32 [B], y i64 [B,Ly] | None, L, NL, loc, step_mode, seed | (seed,
     dropout, drop_seed), *weights)
       -> h_top [L,B,C] (time-major top-layer states), att [L,B,T'] (non-differentiable)."""
+
+    persistent_bwd = True       # (tests switch it off to compare against the per-step BPTT kernels)
 
     @staticmethod
     def forward(ctx, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, *weights):
@@ -214,6 +216,12 @@ class DecoderFn(torch.autograd.Function):
         if loc:
             Bw.update(df=torch.empty(L, B, LOC_C, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
                       acc=torch.empty(B, accf, **f32))
+        if 'pk_ws' in S and DecoderFn.persistent_bwd:    # the forward ran as one persistent launch: so does the BPTT chain
+            nb = L_.las_decoder_pk_bwd_workspace_bytes(ctypes.byref(d))
+            if nb:
+                Bw['pk_ws'] = torch.empty(nb, dtype=torch.uint8, device=dev)
+                Bw['pk_status'] = S['pk_status']
+        DecoderFn.last_pk_bwd_ws = Bw.get('pk_ws')      # (tools/pk_stamps.py reads the diagnostic build's cycle stamps from it)
         bw = DecBwdState()
         for k, v in Bw.items():
             setattr(bw, k, v.data_ptr())

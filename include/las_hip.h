@@ -181,7 +181,11 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
     float* acc;                     /* loc: [B][las_decoder_loc_acc_floats(A)] per-utterance partial sums:
                                        d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad to 4 | d conv_w [10*201] */
     float* demb;                    /* [V][C] d loss / d embed.weight */
+    void* pk_ws;                    /* las_decoder_pk_bwd_workspace_bytes(dims) bytes, or NULL: with it (and the conditions of the
+                                       forward's pk_ws) the whole BPTT chain runs as ONE persistent launch (decoder_pk_bwd.hip) */
+    int32_t* pk_status;             /* int32, caller-zeroed: LAS_E_TIMEOUT if a hand-off spin of that launch ran out */
 } las_dec_bwd_state;
+size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* dims);
 int64_t las_decoder_loc_acc_floats(int A);
 int las_decoder_att_chunks(int Tp);
 /* g_htop [L][B][C]: gradient wrt the top-layer hidden state of every step (from char_trans).  After this call

@@ -255,3 +255,52 @@ def test_persistent_loop_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L)
         else:
             np.testing.assert_allclose(a1, a0, err_msg=k, **tol)
     assert np.array_equal(S1['tok'].cpu().numpy(), S0['tok'].cpu().numpy())
+
+
+@pytest.mark.parametrize('prec,B,Tp,E,A,C,V,L', [('f32', 5, 150, 48, 40, 32, 31, 6), ('bf16', 5, 150, 48, 40, 32, 31, 6),
+                                                 ('f32', 12, 77, 96, 130, 64, 17, 5), ('f32', 3, 9, 16, 7, 6, 9, 4),
+                                                 ('bf16', 24, 300, 640, 300, 320, 31, 7), ('bf16', 12, 300, 640, 300, 320, 31, 4)])
+def test_persistent_bptt_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L):
+    """The one-launch BPTT chain (decoder_pk_bwd.hip) against the three launches per step of decoder_bwd.hip, both fed by
+    the SAME persistent forward: every gradient DecoderFn returns.  f32: 2e-5 + 2e-4 of the largest entry (summation
+    orders differ); bf16: 3e-2 of the largest entry (the persistent chain also exchanges the K-split pieces, d q_pre and
+    d u in bf16, the MFMA operand format of this mode)."""
+    ops, dec = mods
+    rng = np.random.RandomState(B * 1000 + Tp + L + 3)
+    W = rand_weights(rng, V, C, E, A, 1, True)
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    names = dec.weight_names(1, True)
+    res = []
+    ops.set_precision(prec)
+    try:
+        for persistent in (True, False):
+            dec.DecoderFn.persistent_bwd = persistent
+            Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+            enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+            psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+            status = torch.zeros(1, dtype=torch.int32, device=DEV)
+            h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                             torch.tensor(y, device=DEV), L, 1, True, None, dict(seed=0, status=status),
+                                             *[Wg[k] for k in names])
+            (h_top * torch.tensor(G, device=DEV)).sum().backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            res.append(dict({'d enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
+                            **{k: Wg[k].grad.cpu().numpy() for k in names if not k.startswith('char_trans')}))
+    finally:
+        dec.DecoderFn.persistent_bwd = True
+        ops.set_precision('bf16')
+    for k in res[0]:
+        ref, got = res[1][k], res[0][k]
+        lim = (2e-5 + 2e-4 * np.abs(ref).max()) if prec == 'f32' else 3e-2 * np.abs(ref).max() + 1e-6
+        if k == 'attention.gen_energy.bias' and prec == 'bf16':
+            continue            # d b_e = sum of d e, which the softmax makes cancel to 0: what is left is rounding, not signal
+                                # (the per-step path's `dot` from the saved context leaves 2e-2 at the C2 shape, this one 2e-6)
+        assert np.abs(got - ref).max() <= lim, (k, float(np.abs(got - ref).max()), float(lim))

@@ -23,7 +23,7 @@ for it in range(3):
     e1.record(); torch.cuda.synchronize()
 print('forward %.3f ms = %.2f us/step' % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / L), 'status', int(S['pk_status'].item()))
 sync_bytes = (1 + 4 + 4 + 32 + 32) * 256
-dbg = S['pk_ws'][sync_bytes:sync_bytes + 256 * 12 * 8].view(torch.int64).view(256, 12).cpu().numpy().astype(np.float64) / L
+dbg = S['pk_ws'][sync_bytes:sync_bytes + 256 * 20 * 8].view(torch.int64).view(256, 20).cpu().numpy().astype(np.float64) / L
 rows = dbg[dbg.sum(1) > 0]
 ncell = int(os.environ.get('NCELL', 80))
 names_c = ['q tile+signal', 'h-part mma', 'WAIT ctx', 'pull ctx+mma', 'pointwise+publish h', 'saved stores', 'WAIT h', 'pull h']
@@ -32,3 +32,33 @@ for nm, r, names in (('cell', rows[:ncell], names_c), ('att', rows[ncell:], name
     print(nm, 'workgroups', len(r), 'cycles/step total %.0f' % r.sum(1).mean())
     for i, n in enumerate(names):
         print('   %-22s mean %7.0f  min %7.0f  max %7.0f' % (n, r[:, i].mean(), r[:, i].min(), r[:, i].max()))
+
+
+# ---- backward chain
+names = dec.weight_names(1, True)
+Wg = {k: W[k].clone().requires_grad_(True) for k in names}
+enc_g, psi_g = enc.clone().requires_grad_(True), psi.clone().requires_grad_(True)
+G = torch.randn(L, B, C, device='cuda')
+for it in range(2):
+    h_top, att = dec.DecoderFn.apply(enc_g, psi_g, lens_t, y, L, 1, True, None, dict(seed=0, status=torch.zeros(1, dtype=torch.int32, device='cuda')),
+                                     *[Wg[k] for k in names])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    (h_top * G).sum().backward()
+    e1.record(); ops.join_side_stream(); torch.cuda.synchronize()
+print('backward (chain + post-loop + wgrads on side stream) %.3f ms' % e0.elapsed_time(e1))
+ws = dec.DecoderFn.last_pk_bwd_ws
+if ws is not None:
+    sync_bytes = (1 + 4 + 4 * 32) * 256
+    dbg = ws[sync_bytes:sync_bytes + 256 * 20 * 8].view(torch.int64).view(256, 20).cpu().numpy().astype(np.float64) / L
+    rows = dbg[dbg.sum(1) > 0]
+    nc = int(os.environ.get('NCELL_B', 80))
+    names_c = ['load saved', 'WAIT pieces+pull', 'WAIT dq_pre', 'pull dq+mma+sum', 'pw+Ksplit+publish', 'saved stores']
+    names_a = ['A3: conv + reduce', '1-u^2 (mfma+tanh)', 'WAIT pieces', 'C2: signal da', 'WAIT da', 'softmax bwd', 'E5: signal dqp/df',
+               'WAIT dq partials', 'dq_pre+publish', 'A1: s/att/f loads', 'A2: WAIT df + window load', 'B: piece sum', 'C1: da loop + stores',
+               'E1: dz,du->LDS', 'E2: dq reduce+stores', 'E3: df mfma+adds', 'E4: dfx stores']
+    for nm, r, nms in (('cell', rows[:nc], names_c), ('att', rows[nc:], names_a)):
+        print(nm, 'workgroups', len(r), 'cycles/step (sum of medians) %.0f' % sum(np.median(r[:, i]) for i in range(len(nms))))
+        for i, n_ in enumerate(nms):
+            print('   %-28s median %7.0f  min %7.0f  p90 %7.0f' % (n_, np.median(r[:, i]), r[:, i].min(), np.percentile(r[:, i], 90)))

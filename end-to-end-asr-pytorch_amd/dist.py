@@ -73,39 +73,65 @@ def _comm_stream():
     return _COMM['stream']
 
 
+class BucketPlan:
+    """Which flat-gradient ranges go out when: ready(lo) = "every gradient at offsets >= lo has been enqueued" returns the
+    not-yet-sent ranges [lo, previous boundary) cut into pieces of <= bucket_elems; together the calls cover [0, n) once."""
+
+    def __init__(self, n, bucket_elems):
+        self.hi, self.bucket = int(n), int(bucket_elems)
+
+    def ready(self, lo):
+        lo = max(0, min(int(lo), self.hi))
+        out = [(off, min(off + self.bucket, self.hi)) for off in range(lo, self.hi, self.bucket)]
+        self.hi = lo
+        return out
+
+
 def backward_with_overlap(loss, model, bucket_elems=64 * 1024 * 1024):
     """loss.backward() + the gradient exchange.  Single process: just backward and the side-stream join."""
     from . import ops
     flat = model.flat_grads
-    if not dist.is_initialized() or dist.get_world_size() == 1 or not flat.is_cuda:
+    # Overlap only over RCCL (backend 'nccl'): its collectives are device-side work on a stream of their own.  gloo moves HIP
+    # tensors through host copies issued by worker threads; launched in the middle of backward (two ranks rehearsing on ONE
+    # GPU, persistent kernels of both resident) each of its collectives then took 2-3 s (measured: 13 s per step against
+    # 0.12 s with the exchange after backward), so gloo keeps the exchange after backward.  LAS_DIST_NO_OVERLAP=1 forces that.
+    if (not dist.is_initialized() or dist.get_world_size() == 1 or not flat.is_cuda or os.environ.get('LAS_DIST_NO_OVERLAP')
+            or dist.get_backend() != 'nccl'):
         loss.backward()
         ops.join_side_stream()
         allreduce_grads(flat)
         return
-    st = {'hi': flat.numel(), 'works': []}
+    st = {'works': []}
+    plan = BucketPlan(flat.numel(), bucket_elems)
     comm = _comm_stream()
     base = flat.data_ptr()
 
     def ready(lo):
         """everything at flat offsets >= lo has been enqueued (main or side stream)"""
-        lo = max(0, min(int(lo), st['hi']))
-        if lo >= st['hi']:
+        ranges = plan.ready(lo)
+        if not ranges:
             return
         comm.wait_stream(torch.cuda.current_stream())
         if ops._SIDE['stream'] is not None:
             comm.wait_stream(ops._SIDE['stream'])
         with torch.cuda.stream(comm):                         # the collective's stream waits for comm's tail only
-            for off in range(lo, st['hi'], bucket_elems):
-                st['works'].append(dist.all_reduce(flat[off:min(off + bucket_elems, st['hi'])], op=dist.ReduceOp.SUM,
-                                                   async_op=True))
-        st['hi'] = lo
+            for off, end in ranges:
+                st['works'].append(dist.all_reduce(flat[off:end], op=dist.ReduceOp.SUM, async_op=True))
 
+    dbg = os.environ.get('LAS_DIST_DEBUG') and dist.get_rank() == 0
+    import time
+    t0 = time.perf_counter()
     ops._GRAD_READY = lambda first_grad: ready((first_grad.data_ptr() - base) // 4)
     try:
         loss.backward()
     finally:
         ops._GRAD_READY = None
+    t1 = time.perf_counter()
     ops.join_side_stream()
     ready(0)
+    t2 = time.perf_counter()
     for w in st['works']:
         w.wait()                                              # the current stream waits for the collective
+    if dbg:
+        print('[dist] backward enqueue %.1f ms, last bucket %.1f ms, waits %.1f ms, %d collectives' %
+              ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3, len(st['works'])), flush=True)

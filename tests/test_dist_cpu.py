@@ -64,3 +64,22 @@ def test_sharded_allreduce_equals_full_batch():
     ref = torch.cat([st.W[k].grad.reshape(-1) for k in names]).numpy()
     assert abs(loss - float(full)) < 1e-5
     np.testing.assert_allclose(flat, ref, atol=2e-6)
+
+
+def test_bucket_plan_covers_the_flat_gradient_once():
+    """dist.backward_with_overlap's bookkeeping: the ranges sent at the successive "layer l and everything after it is
+    final" calls (the encoder layers' first-parameter offsets, descending, then 0) are disjoint, cover [0, n) exactly once
+    and respect the bucket size; a repeated or out-of-order call sends nothing twice."""
+    sys.path.insert(0, ROOT)
+    ldist = importlib.import_module('end-to-end-asr-pytorch_amd.dist')
+    n = 1000
+    plan = ldist.BucketPlan(n, 300)
+    sent = []
+    for lo in [700, 700, 820, 410, 64, 0, 0]:
+        sent += plan.ready(lo)
+    assert all(0 < e - o <= 300 for o, e in sent)
+    cover = np.zeros(n, int)
+    for o, e in sent:
+        cover[o:e] += 1
+    assert (cover == 1).all()
+    assert sent[0] == (700, 1000) and sent[-1][0] == 0

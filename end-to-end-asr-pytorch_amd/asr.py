@@ -41,11 +41,14 @@ class FlatParams:
         total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         module.flat_params = torch.zeros(total, dtype=torch.float32, device=device)
         module.flat_grads = torch.zeros(total, dtype=torch.float32, device=device)
+        # bf16 shadow of the weights: operand of the GEMMs in bf16 mode, rewritten by the fused optimiser kernels
+        module.flat_params16 = torch.zeros(total, dtype=torch.bfloat16, device=device)
         module.param_slices = {}
         for (name, shape), off in zip(self.specs, offs):
             k = math.prod(shape)
             p = nn.Parameter(module.flat_params[off:off + k].view(shape))
             p.grad = module.flat_grads[off:off + k].view(shape)
+            p._bf16 = module.flat_params16[off:off + k].view(shape)
             module.param_slices[name] = (off, k, shape)
             # register under the reference's dotted name
             obj = module
@@ -163,10 +166,15 @@ class Seq2Seq(nn.Module):
             obj = getattr(obj, q)
         return obj
 
-    def _cat(self, prefix, kind, shape, grads=False):
-        """Kernel-facing view over the adjacent per-direction parameters (or their gradients), no copy."""
+    def _cat(self, prefix, kind, shape, grads=False, shadow=False):
+        """Kernel-facing view over the adjacent per-direction parameters (or their gradients / bf16 shadow), no copy."""
         off, k, _ = self.param_slices[f'{prefix}.{kind}_l0']
-        return (self.flat_grads if grads else self.flat_params)[off:off + k * self.ND].view(shape)
+        return (self.flat_params16 if shadow else self.flat_grads if grads else self.flat_params)[off:off + k * self.ND].view(shape)
+
+    def sync_bf16(self):
+        """Refresh the weights' bf16 shadow after the fp32 weights were written by anything but the fused optimiser."""
+        if self.flat_params.is_cuda:
+            ops.cast_bf16(self.flat_params, out=self.flat_params16)
 
     def init_parameters(self):
         """Same scheme as reference asr.py:114-153 (LeCun normal; decoder forget-gate bias_ih = 1; embed N(0,1))."""
@@ -185,12 +193,14 @@ class Seq2Seq(nn.Module):
                     b = self.P(f'decoder.layer{l}.bias_ih')
                     n = b.shape[0]
                     b[n // 4:n // 2].fill_(1.0)
+        self.sync_bf16()
 
     def load_reference_state(self, state):
         """Copy weights given under the reference's state_dict names (numpy arrays or tensors)."""
         with torch.no_grad():
             for name, p in self.named_parameters():
                 p.copy_(torch.as_tensor(state[name]).to(p.device, torch.float32).view(p.shape))
+        self.sync_bf16()
 
     # -- encoder ---------------------------------------------------------------------------------------------
     def encode(self, x, lens_dev, lens_host):
@@ -208,13 +218,14 @@ class Seq2Seq(nn.Module):
             I_ = self.enc_in[l]
             T_l = max(lens_host)                 # pad_packed_sequence trims to the longest utterance (asr.py:483)
             if h.shape[0] > T_l:
-                h = h[:T_l]
+                h = ops.narrow_rows(h, T_l)
             leaves = []
             for kind in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
                 for s in (['', '_reverse'] if self.bidir else ['']):
                     leaves.append(self.P(f'{pre}.{kind}_l0{s}'))
             cats = (self._cat(pre, 'weight_ih', (self.ND * 4 * H, I_)), self._cat(pre, 'weight_hh', (self.ND, 4 * H, H)),
-                    self._cat(pre, 'bias_ih', (self.ND * 4 * H,)), self._cat(pre, 'bias_hh', (self.ND * 4 * H,)))
+                    self._cat(pre, 'bias_ih', (self.ND * 4 * H,)), self._cat(pre, 'bias_hh', (self.ND * 4 * H,)),
+                    self._cat(pre, 'weight_ih', (self.ND * 4 * H, I_), shadow=True))
             cat_grads = (self._cat(pre, 'weight_ih', (self.ND * 4 * H, I_), True), self._cat(pre, 'weight_hh', (self.ND, 4 * H, H), True),
                          self._cat(pre, 'bias_ih', (self.ND * 4 * H,), True), self._cat(pre, 'bias_hh', (self.ND * 4 * H,), True))
             h = ops.lstm_layer_leaves(h, lens_dev, cats, sr, self.concat, self.status, self.ND, leaves, cat_grads)

@@ -18,11 +18,17 @@ namespace {
 
 using namespace las_tile;
 
-template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC>
+// A16 / B16: that operand is a bf16 matrix in memory (same layout, element strides) -- activation twins written by
+// their producers and the bf16 shadow of the weights; C16 (optional): a bf16 copy of the result for the next consumer.
+template <int PREC, bool A_KCONT, bool B_KCONT, bool VEC, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alpha, const float* __restrict__ A,
                                                   long lda, long sA, const float* __restrict__ B, long ldb, long sB,
                                                   float beta, float* __restrict__ C, long ldc, long sC,
-                                                  const float* __restrict__ bias, int act, int ksplit, int swz) {
+                                                  const float* __restrict__ bias, int act, int ksplit, int swz,
+                                                  bf16_t* __restrict__ C16 = nullptr, long ldc16 = 0) {
+    static_assert(!(A16 || B16) || (PREC == LAS_PREC_BF16 && VEC), "bf16 sources: bf16 mode, aligned operands");
+    const bf16_t* A16p = (const bf16_t*)A;
+    const bf16_t* B16p = (const bf16_t*)B;
     typedef typename Elem<PREC>::T T;
     constexpr int LD = BK + Elem<PREC>::PAD;
     __shared__ __attribute__((aligned(16))) T As2[2][BM * LD];      // double buffered: one barrier per k-tile
@@ -42,7 +48,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         by = t / nx; bx = t - by * nx;
     }
     const int bz = ksplit > 1 ? 0 : bzz;
-    A += (long)bz * sA; B += (long)bz * sB; C += (long)bz * sC;
+    if (A16) A16p += (long)bz * sA; else A += (long)bz * sA;
+    if (B16) B16p += (long)bz * sB; else B += (long)bz * sB;
+    C += (long)bz * sC;
+    if (C16) C16 += (long)bz * sC;
     const int m0 = by * BM, n0 = bx * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     Frag16 ra, rb;
+    Frag8h ha, hb;
     const bool a_full = VEC && (m0 + BM <= M), b_full = VEC && (n0 + BN <= N);
     const float* a_base = A_KCONT ? A + (long)(m0 + (threadIdx.x >> 3)) * lda + (threadIdx.x & 7) * 4
                                   : A + (long)((threadIdx.x >> 5) * 4) * lda + m0 + (threadIdx.x & 31) * 4;
@@ -67,10 +77,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
     if (kt0 >= nk) return;
     {
         const bool k_full = (kt0 + 1) * BK <= K;
-        if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, kt0 * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, kt0 * BK, M, K);
-        if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, kt0 * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, kt0 * BK, N, K);
+        if constexpr (A16) g_load_bf16<A_KCONT>(ha, A16p, lda, m0, kt0 * BK, M, K);
+        else if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, kt0 * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, kt0 * BK, M, K);
+        if constexpr (B16) g_load_bf16<B_KCONT>(hb, B16p, ldb, n0, kt0 * BK, N, K);
+        else if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, kt0 * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, kt0 * BK, N, K);
     }
-    if constexpr (PREC == LAS_PREC_BF16) { tile_store_bf16<A_KCONT>(ra, As2[0]); tile_store_bf16<B_KCONT>(rb, Bs2[0]); }
+    if constexpr (PREC == LAS_PREC_BF16) {
+        if constexpr (A16) tile_store_bf16_src<A_KCONT>(ha, (bf16_t*)As2[0]); else tile_store_bf16<A_KCONT>(ra, As2[0]);
+        if constexpr (B16) tile_store_bf16_src<B_KCONT>(hb, (bf16_t*)Bs2[0]); else tile_store_bf16<B_KCONT>(rb, Bs2[0]);
+    }
     else { s_store<A_KCONT, T, LD>(ra, As2[0]); s_store<B_KCONT, T, LD>(rb, Bs2[0]); }
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
@@ -79,8 +94,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
         const T* Bs = Bs2[cur];
         if (kt + 1 < nk) {                     // next k-tile: global -> registers, in flight across the MFMAs below
             const bool k_full = (kt + 2) * BK <= K;
-            if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, (kt + 1) * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, (kt + 1) * BK, M, K);
-            if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, (kt + 1) * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, (kt + 1) * BK, N, K);
+            if constexpr (A16) g_load_bf16<A_KCONT>(ha, A16p, lda, m0, (kt + 1) * BK, M, K);
+            else if (a_full && k_full) g_load_fast<A_KCONT>(ra, a_base, lda, (kt + 1) * BK); else g_load<A_KCONT, VEC>(ra, A, lda, m0, (kt + 1) * BK, M, K);
+            if constexpr (B16) g_load_bf16<B_KCONT>(hb, B16p, ldb, n0, (kt + 1) * BK, N, K);
+            else if (b_full && k_full) g_load_fast<B_KCONT>(rb, b_base, ldb, (kt + 1) * BK); else g_load<B_KCONT, VEC>(rb, B, ldb, n0, (kt + 1) * BK, N, K);
         }
         if constexpr (PREC == LAS_PREC_BF16) {
             bf16x8 af[4], bfr[4];
@@ -113,7 +130,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
             }
         }
         if (kt + 1 < nk) {                     // registers -> the other LDS buffer (nobody reads it this iteration)
-            if constexpr (PREC == LAS_PREC_BF16) { tile_store_bf16<A_KCONT>(ra, As2[cur ^ 1]); tile_store_bf16<B_KCONT>(rb, Bs2[cur ^ 1]); }
+            if constexpr (PREC == LAS_PREC_BF16) {
+                if constexpr (A16) tile_store_bf16_src<A_KCONT>(ha, (bf16_t*)As2[cur ^ 1]); else tile_store_bf16<A_KCONT>(ra, As2[cur ^ 1]);
+                if constexpr (B16) tile_store_bf16_src<B_KCONT>(hb, (bf16_t*)Bs2[cur ^ 1]); else tile_store_bf16<B_KCONT>(rb, Bs2[cur ^ 1]);
+            }
             else { s_store<A_KCONT, T, LD>(ra, As2[cur ^ 1]); s_store<B_KCONT, T, LD>(rb, Bs2[cur ^ 1]); }
         }
         __syncthreads();
@@ -140,6 +160,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(int M, int N, int K, float alp
                 if (act == LAS_ACT_TANH) v = tanhf(v);
                 else if (act == LAS_ACT_RELU) v = v < 0.f ? 0.f : v;
                 *c = v;
+                if (C16) C16[(long)m * ldc16 + n] = f2bf(v);
             }
         }
     }
@@ -152,6 +173,23 @@ int launch(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float
 #define LAS_GEMM_GO(AK, BK_)                                                                                          \
     hipLaunchKernelGGL((gemm_kernel<PREC, AK, BK_, VEC>), grid, dim3(NT), 0, st, M, N, K, alpha, A, lda, sA, B, ldb, \
                        sB, beta, C, ldc, sC, bias, act, ksplit, swz)
+    if (!ta && tb) LAS_GEMM_GO(true, true);
+    else if (!ta && !tb) LAS_GEMM_GO(true, false);
+    else if (ta && !tb) LAS_GEMM_GO(false, false);
+    else LAS_GEMM_GO(false, true);
+#undef LAS_GEMM_GO
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
+// bf16-source variants (bf16 mode, aligned operands only)
+template <bool A16, bool B16>
+int launch16(int ta, int tb, dim3 grid, hipStream_t st, int M, int N, int K, float alpha, const void* A, long lda, long sA,
+             const void* B, long ldb, long sB, float beta, float* C, long ldc, long sC, const float* bias, int act, int ksplit,
+             int swz, bf16_t* C16, long ldc16) {
+#define LAS_GEMM_GO(AK, BK_)                                                                                              \
+    hipLaunchKernelGGL((gemm_kernel<LAS_PREC_BF16, AK, BK_, true, A16, B16>), grid, dim3(NT), 0, st, M, N, K, alpha,        \
+                       (const float*)A, lda, sA, (const float*)B, ldb, sB, beta, C, ldc, sC, bias, act, ksplit, swz, C16, ldc16)
     if (!ta && tb) LAS_GEMM_GO(true, true);
     else if (!ta && !tb) LAS_GEMM_GO(true, false);
     else if (ta && !tb) LAS_GEMM_GO(false, false);
@@ -192,30 +230,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 }  // namespace
 
-extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A,
-                        int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta,
-                        float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch,
-                        void* stream) {
+static int gemm_common(int prec, int transA, int transB, int M, int N, int K, float alpha, const void* A, int a16,
+                       int64_t lda, int64_t strideA, const void* B, int b16, int64_t ldb, int64_t strideB, float beta,
+                       float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch, void* C16,
+                       int64_t ldc16, void* stream) {
     LAS_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0 && batch >= 1);
     LAS_CHECK_ARG(prec == LAS_PREC_BF16 || prec == LAS_PREC_F32);
     LAS_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
+    LAS_CHECK_ARG(!C16 || ldc16 >= N);
     if (M == 0 || N == 0) return LAS_OK;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     if (grid.y > 65535 || grid.z > 65535) return LAS_E_UNSUPPORTED;
     // split-K for the weight-gradient shapes (few output tiles, K = T*B in the tens of thousands)
     int ksplit = 1;
     const long tiles = (long)grid.x * grid.y;
-    if (batch == 1 && !bias && act == LAS_ACT_NONE && tiles < 256 && K >= 2048) {
+    if (batch == 1 && !bias && act == LAS_ACT_NONE && !C16 && tiles < 256 && K >= 2048) {
         ksplit = (int)((512 + tiles - 1) / tiles);
         const int nk = (K + BK - 1) / BK;
         if (ksplit > nk / 8) ksplit = nk / 8;
         if (ksplit > 512) ksplit = 512;          // (one-tile outputs with K in the 10^5..10^6: the first conv layer's dW)
         if (ksplit < 1) ksplit = 1;
     }
-    // fast path: every operand vector is a whole, 16-byte aligned float4 inside the matrix
-    const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (((uintptr_t)A & 15) == 0) && (transA ? M % 4 == 0 : K % 4 == 0);
-    const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (((uintptr_t)B & 15) == 0) && (transB ? K % 4 == 0 : N % 4 == 0);
-    const bool vec = vecA && vecB && K >= 4 && M >= 4 && N >= 4;
+    // fast path: every operand vector is a whole, 16-byte aligned vector inside the matrix (4 floats / 8 bf16)
+    const int va = a16 ? 8 : 4, vb = b16 ? 8 : 4;
+    const bool vecA = (lda % va == 0) && (strideA % va == 0) && (((uintptr_t)A & 15) == 0) && (transA ? M % va == 0 : K % va == 0);
+    const bool vecB = (ldb % vb == 0) && (strideB % vb == 0) && (((uintptr_t)B & 15) == 0) && (transB ? K % vb == 0 : N % vb == 0);
+    const bool vec = vecA && vecB && K >= 8 && M >= 8 && N >= 8;
+    if ((a16 || b16) && (!vec || prec != LAS_PREC_BF16)) return LAS_E_UNSUPPORTED;       // (the caller falls back to its fp32 copy)
     hipStream_t st = (hipStream_t)stream;
     static const int swz_env = getenv("LAS_GEMM_NOSWZ") ? 0 : 1;
     if (ksplit > 1) grid.z = ksplit;
@@ -224,10 +265,40 @@ extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, f
         hipLaunchKernelGGL(scale2d_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, beta, N, C, (long)ldc);
         LAS_LAUNCH_OK();
     }
-#define LAS_GEMM_ARGS transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit, swz
+    if (a16 || b16) {
+#define LAS_G16_ARGS transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit, swz, (bf16_t*)C16, ldc16
+        if (a16 && b16) return launch16<true, true>(LAS_G16_ARGS);
+        if (a16) return launch16<true, false>(LAS_G16_ARGS);
+        return launch16<false, true>(LAS_G16_ARGS);
+#undef LAS_G16_ARGS
+    }
+    if (C16) {                                   // fp32 sources with a bf16 copy of the result: the bf16-mode kernel family
+        if (prec != LAS_PREC_BF16 || !vec) return LAS_E_UNSUPPORTED;
+        return launch16<false, false>(transA, transB, grid, st, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc,
+                                      strideC, bias, act, ksplit, swz, (bf16_t*)C16, ldc16);
+    }
+    const float* Af = (const float*)A;
+    const float* Bf = (const float*)B;
+#define LAS_GEMM_ARGS transA, transB, grid, st, M, N, K, alpha, Af, lda, strideA, Bf, ldb, strideB, beta, C, ldc, strideC, bias, act, ksplit, swz
     if (prec == LAS_PREC_BF16) return vec ? launch<LAS_PREC_BF16, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_BF16, false>(LAS_GEMM_ARGS);
     return vec ? launch<LAS_PREC_F32, true>(LAS_GEMM_ARGS) : launch<LAS_PREC_F32, false>(LAS_GEMM_ARGS);
 #undef LAS_GEMM_ARGS
+}
+
+extern "C" int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                        int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta,
+                        float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch,
+                        void* stream) {
+    return gemm_common(prec, transA, transB, M, N, K, alpha, A, 0, lda, strideA, B, 0, ldb, strideB, beta, C, ldc, strideC, bias, act,
+                       batch, nullptr, 0, stream);
+}
+
+extern "C" int las_gemm_ex(int prec, int transA, int transB, int M, int N, int K, float alpha, const void* A, int a_bf16,
+                           int64_t lda, int64_t strideA, const void* B, int b_bf16, int64_t ldb, int64_t strideB, float beta,
+                           float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch, void* C16,
+                           int64_t ldc16, void* stream) {
+    return gemm_common(prec, transA, transB, M, N, K, alpha, A, a_bf16, lda, strideA, B, b_bf16, ldb, strideB, beta, C, ldc, strideC,
+                       bias, act, batch, C16, ldc16, stream);
 }
 
 extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {

@@ -6,6 +6,7 @@
 namespace las_tile {
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 template <int PREC> struct Elem;
 template <> struct Elem<LAS_PREC_BF16> { typedef bf16_t T; static constexpr int PAD = 8; };   // 16 B
@@ -131,5 +132,48 @@ __device__ __forceinline__ bf16x8 tile_frag_bf16(const bf16_t* __restrict__ tile
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+
+
+// ---- bf16 SOURCE operands (activation twins written by their producers, the bf16 shadow of the weights): half the
+// L2 -> LDS bytes of an fp32 source and no conversion while staging.  One thread stages two 16-byte vectors per tile.
+// KCONT: vector = 8 consecutive k of one row (row = tid/4 + 64 p, k8 = 8 (tid % 4)); k-strided: 8 consecutive rows of
+// one k (k = tid/16 + 16 p, r8 = 8 (tid % 16)).  Callers guarantee 16-byte aligned bases, ld % 8 == 0 and K % 8 == 0
+// (KCONT) / rows % 8 == 0 (k-strided); vectors outside the matrix come from clamped addresses and are zeroed.
+struct Frag8h { u32x4_t v[2]; };
+template <bool KCONT>
+__device__ __forceinline__ void g_load_bf16(Frag8h& reg, const bf16_t* __restrict__ src, long ld, int row0, int k0, int rows, int K) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        int r, k;
+        if (KCONT) { r = row0 + (tid >> 2) + 64 * p; k = k0 + (tid & 3) * 8; }
+        else       { k = k0 + (tid >> 4) + 16 * p;  r = row0 + (tid & 15) * 8; }
+        const bool ok = r < rows && k < K;
+        const int rc = KCONT ? min(r, rows - 1) : min(r, rows - 8);
+        const int kc = KCONT ? min(k, K - 8) : min(k, K - 1);
+        const bf16_t* q = KCONT ? src + (long)rc * ld + kc : src + (long)kc * ld + rc;
+        const u32x4_t t = *reinterpret_cast<const u32x4_t*>(__builtin_assume_aligned(q, 16));
+        reg.v[p] = ok ? t : (u32x4_t){0u, 0u, 0u, 0u};
+    }
+}
+template <bool KCONT>
+__device__ __forceinline__ void tile_store_bf16_src(const Frag8h& reg, bf16_t* __restrict__ tile) {
+    constexpr int LD = BK + Elem<LAS_PREC_BF16>::PAD;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (KCONT) {
+            // the [row][k] image keeps its eight 4-element k chunks in the slot order of the transposing read (see above):
+            // logical chunk c sits at position (c < 4 ? 8 c : 8 (c - 4) + 4); my vector is chunks 2 v and 2 v + 1
+            const int r = (tid >> 2) + 64 * p, v = tid & 3, c0 = 2 * v, c1 = 2 * v + 1;
+            const int p0 = c0 < 4 ? 8 * c0 : 8 * (c0 - 4) + 4, p1 = c1 < 4 ? 8 * c1 : 8 * (c1 - 4) + 4;
+            *(uint2*)(tile + r * LD + p0) = make_uint2(reg.v[p][0], reg.v[p][1]);
+            *(uint2*)(tile + r * LD + p1) = make_uint2(reg.v[p][2], reg.v[p][3]);
+        } else {
+            const int k = (tid >> 4) + 16 * p, r = (tid & 15) * 8;
+            *(u32x4_t*)(tile + k * LDK + r) = reg.v[p];
+        }
+    }
+}
 
 }  // namespace las_tile

@@ -17,18 +17,31 @@ __global__ __launch_bounds__(256) void transpose01_kernel(const float* __restric
     }
 }
 
-// out = dy * (1 - y^2)        (backward of y = tanh(.), reference asr.py:316)
+// out = dy * (1 - y^2)        (backward of y = tanh(.), reference asr.py:316); out16 (optional): its bf16 twin
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                       float* __restrict__ out, long n) {
+                                                       float* __restrict__ out, bf16_t* __restrict__ out16, long n) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 256 * 4;
     for (; i + 3 < n; i += stride) {
         const float4 a = *(const float4*)(dy + i), b = *(const float4*)(y + i);
-        *(float4*)(out + i) = make_float4(a.x * (1.f - b.x * b.x), a.y * (1.f - b.y * b.y), a.z * (1.f - b.z * b.z),
-                                          a.w * (1.f - b.w * b.w));
+        const float4 o = make_float4(a.x * (1.f - b.x * b.x), a.y * (1.f - b.y * b.y), a.z * (1.f - b.z * b.z), a.w * (1.f - b.w * b.w));
+        *(float4*)(out + i) = o;
+        if (out16) store4_ct(out16 + i, o.x, o.y, o.z, o.w);
     }
     if (i < n && i + 3 >= n)
-        for (long k = i; k < n; ++k) out[k] = dy[k] * (1.f - y[k] * y[k]);
+        for (long k = i; k < n; ++k) { const float o = dy[k] * (1.f - y[k] * y[k]); out[k] = o; if (out16) out16[k] = f2bf(o); }
+}
+
+// out16 = bf16(in): the bf16 twin of an activation whose producer does not write one itself (HBM-bound: 6 bytes per element)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    const long stride = (long)gridDim.x * 256 * 8;
+    for (; i + 7 < n; i += stride) {
+        const float4 a = *(const float4*)(in + i), b = *(const float4*)(in + i + 4);
+        *(uint4*)(out + i) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+    if (i < n && i + 7 >= n)
+        for (long k = i; k < n; ++k) out[k] = f2bf(in[k]);
 }
 
 // lens[b] = #frames whose feature sum != 0   (reference solver.py:134, done on the host there).
@@ -95,13 +108,30 @@ extern "C" int las_transpose01(const float* in, float* out, int D0, int D1, int 
     return LAS_OK;
 }
 
-extern "C" int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+static int tanh_bwd_launch(const float* dy, const float* y, float* out, void* out16, int64_t n, void* stream) {
     LAS_CHECK_ARG(dy && y && out && n >= 0);
+    LAS_CHECK_ARG(!out16 || (((uintptr_t)out16) & 7) == 0);
     if (n == 0) return LAS_OK;
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, (long)n);
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, (bf16_t*)out16, (long)n);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+extern "C" int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+    return tanh_bwd_launch(dy, y, out, nullptr, n, stream);
+}
+extern "C" int las_tanh_bwd_twin(const float* dy, const float* y, float* out, void* out_bf16, int64_t n, void* stream) {
+    return tanh_bwd_launch(dy, y, out, out_bf16, n, stream);
+}
+extern "C" int las_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream) {
+    LAS_CHECK_ARG(in && out_bf16 && n >= 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out_bf16) & 15) == 0);
+    if (n == 0) return LAS_OK;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out_bf16, (long)n);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

@@ -69,7 +69,7 @@ __device__ __forceinline__ void adadelta_one(float& p, float g, float& sq, float
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                    const float* __restrict__ nrm, const int32_t* __restrict__ step,
-                                                   int zero_grad) {
+                                                   int zero_grad, bf16_t* __restrict__ p16) {
     const bool skip = nrm[2] != 0.f;
     const float coef = nrm[1];
     const double t = (double)step[0];
@@ -85,12 +85,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             adam_one(pp.z, gg.z, mm.z, vv.z, coef, b1, b2, eps, step_size, bc2s);
             adam_one(pp.w, gg.w, mm.w, vv.w, coef, b1, b2, eps, step_size, bc2s);
             ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+            if (p16) store4_ct(p16 + 4 * i, pp.x, pp.y, pp.z, pp.w);      // bf16 shadow of the weights (GEMM operands)
         }
         if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
-        if (!skip) adam_one(p[i], g[i], m[i], v[i], coef, b1, b2, eps, step_size, bc2s);
+        if (!skip) { adam_one(p[i], g[i], m[i], v[i], coef, b1, b2, eps, step_size, bc2s); if (p16) p16[i] = f2bf(p[i]); }
         if (zero_grad) g[i] = 0.f;
     }
 }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ sq, float* __restrict__ acc, long n, float lr,
                                                        float rho, float eps, const float* __restrict__ nrm,
-                                                       int zero_grad) {
+                                                       int zero_grad, bf16_t* __restrict__ p16) {
     const bool skip = nrm[2] != 0.f;
     const float coef = nrm[1];
     const long n4 = n >> 2;
@@ -111,12 +112,13 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, fl
             adadelta_one(pp.z, gg.z, ss.z, aa.z, coef, lr, rho, eps);
             adadelta_one(pp.w, gg.w, ss.w, aa.w, coef, lr, rho, eps);
             ((float4*)p)[i] = pp; ((float4*)sq)[i] = ss; ((float4*)acc)[i] = aa;
+            if (p16) store4_ct(p16 + 4 * i, pp.x, pp.y, pp.z, pp.w);
         }
         if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = (n4 << 2) + threadIdx.x;
-        if (!skip) adadelta_one(p[i], g[i], sq[i], acc[i], coef, lr, rho, eps);
+        if (!skip) { adadelta_one(p[i], g[i], sq[i], acc[i], coef, lr, rho, eps); if (p16) p16[i] = f2bf(p[i]); }
         if (zero_grad) g[i] = 0.f;
     }
 }
@@ -143,21 +145,21 @@ extern "C" int las_grad_norm(const float* g, int64_t n, float gscale, float max_
 }
 
 extern "C" int las_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                             const float* norm3, const int32_t* step_dev, int zero_grad, void* stream) {
+                             const float* norm3, const int32_t* step_dev, int zero_grad, void* p_bf16, void* stream) {
     LAS_CHECK_ARG(p && g && m && v && norm3 && step_dev && n > 0);
     LAS_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, b1, b2, eps,
-                       norm3, step_dev, zero_grad);
+                       norm3, step_dev, zero_grad, (bf16_t*)p_bf16);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }
 
 extern "C" int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps,
-                                 const float* norm3, int zero_grad, void* stream) {
+                                 const float* norm3, int zero_grad, void* p_bf16, void* stream) {
     LAS_CHECK_ARG(p && g && sq && acc && norm3 && n > 0);
     LAS_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)sq) | ((uintptr_t)acc)) & 15) == 0);
     hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, sq, acc, (long)n, lr, rho,
-                       eps, norm3, zero_grad);
+                       eps, norm3, zero_grad, (bf16_t*)p_bf16);
     LAS_LAUNCH_OK();
     return LAS_OK;
 }

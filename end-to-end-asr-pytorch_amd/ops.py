@@ -211,8 +211,11 @@ LL = __import__('ctypes').c_longlong
 
 # ----------------------------------------------------------------------------- GEMM
 def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=None, act=0, M=None, N=None,
-         K=None, lda=None, ldb=None, ldc=None, batch=1, sA=0, sB=0, sC=0):
-    """Raw las_gemm call on 2-D (or strided-batched) row-major fp32 HIP tensors.  Returns C."""
+         K=None, lda=None, ldb=None, ldc=None, batch=1, sA=0, sB=0, sC=0, A16=None, B16=None, C16=None):
+    """Raw las_gemm call on 2-D (or strided-batched) row-major fp32 HIP tensors.  Returns C.
+    A16 / B16: bf16 twins of A / B (same shape and strides); in bf16 mode the kernel then reads those (half the bytes, no
+    conversion while staging).  C16: a bf16 tensor shaped like C that also receives the result (a twin for the next
+    consumer).  In f32 mode the twins are ignored (C16 is then filled by a cast)."""
     L_ = _lib.lib()
     if M is None:
         M = A.shape[-1] if transA else A.shape[-2]
@@ -228,11 +231,78 @@ def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=Non
         if batch > 1:
             sC = M * N
     ldc = ldc if ldc is not None else C.stride(-2)
+    use16 = _prec == 0 and USE_BF16_TWINS and (A16 is not None or B16 is not None or C16 is not None)
     with _Timed('gemm_kernel (all layouts / epilogues)', 2.0 * M * N * K * batch, 'flop'):
-        check(L_.las_gemm(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha), P(A.data_ptr()), LL(lda),
-                          LL(sA), P(B.data_ptr()), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc), LL(sC),
-                          P(bias.data_ptr()) if bias is not None else None, I(act), I(batch), cur_stream()), 'las_gemm')
+        rc = -2
+        if use16:
+            a16, b16 = A16 is not None, B16 is not None
+            rc = L_.las_gemm_ex(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha),
+                                P((A16 if a16 else A).data_ptr()), I(int(a16)), LL(lda), LL(sA),
+                                P((B16 if b16 else B).data_ptr()), I(int(b16)), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc),
+                                LL(sC), P(bias.data_ptr()) if bias is not None else None, I(act), I(batch),
+                                P(C16.data_ptr()) if C16 is not None else None, LL(C16.stride(-2) if C16 is not None else 0),
+                                cur_stream())
+            if rc not in (0, -2):
+                check(rc, 'las_gemm_ex')
+        if rc == -2:                                    # no twins / operands not aligned for them: the fp32 sources
+            check(L_.las_gemm(I(_prec), I(int(transA)), I(int(transB)), I(M), I(N), I(K), F(alpha), P(A.data_ptr()), LL(lda),
+                              LL(sA), P(B.data_ptr()), LL(ldb), LL(sB), F(beta), P(C.data_ptr()), LL(ldc), LL(sC),
+                              P(bias.data_ptr()) if bias is not None else None, I(act), I(batch), cur_stream()), 'las_gemm')
+            if C16 is not None:
+                C16.copy_(C)
     return C
+
+
+USE_BF16_TWINS = True       # (tests / A-B measurements switch the bf16 operand twins off)
+TWIN_MIN_ELEMS = 1 << 18    # below this an operand is not worth a cast pass: the GEMM converts it while staging
+
+
+def twins_on():
+    return _prec == 0 and USE_BF16_TWINS
+
+
+def cast_bf16(x, out=None):
+    """bf16 copy of a contiguous fp32 HIP tensor (las_cast_bf16)."""
+    L_ = _lib.lib()
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(L_.las_cast_bf16(ptr(x), P(out.data_ptr()), LL(x.numel()), cur_stream()), 'las_cast_bf16')
+    return out
+
+
+def twin(x, make=False):
+    """The bf16 twin a producer attached to `x` (tensor attribute `_bf16`), or -- make=True, bf16 mode, big enough -- a
+    fresh cast; None otherwise.  A twin is only trusted if it has x's shape and strides."""
+    if not twins_on() or x is None:
+        return None
+    t = getattr(x, '_bf16', None)
+    if t is not None and t.shape == x.shape and t.stride() == x.stride() and t.dtype == torch.bfloat16:
+        return t
+    if make and x.numel() >= TWIN_MIN_ELEMS and x.is_contiguous() and x.data_ptr() % 16 == 0:
+        t = cast_bf16(x)
+        try:
+            x._bf16 = t                      # (a second consumer of the same tensor finds it)
+        except Exception:
+            pass
+        return t
+    return None
+
+
+def with_twin(y, y16):
+    if y16 is not None:
+        y._bf16 = y16
+    return y
+
+
+def narrow_rows(x, n):
+    """x[:n] that keeps the bf16 twin."""
+    t = getattr(x, '_bf16', None)
+    y = x[:n]
+    if t is not None:
+        y._bf16 = t[:n]
+    return y
+
 
 
 def colsum(X, out, beta=0.0, M=None, N=None, ld=None):
@@ -265,12 +335,17 @@ class Transpose01Fn(torch.autograd.Function):
         return transpose01(g)
 
 
-def tanh_bwd(dy, y):
+def tanh_bwd(dy, y, want_twin=False):
+    """dy * (1 - y^2); want_twin (bf16 mode): also its bf16 twin, written by the same kernel -> (out, out16 | None)."""
     L_ = _lib.lib()
     dy, y = dy.contiguous(), y.contiguous()
     out = torch.empty_like(y)
+    if want_twin and twins_on() and y.numel() >= TWIN_MIN_ELEMS:
+        out16 = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+        check(L_.las_tanh_bwd_twin(ptr(dy), ptr(y), ptr(out), P(out16.data_ptr()), LL(y.numel()), cur_stream()), 'las_tanh_bwd_twin')
+        return out, out16
     check(L_.las_tanh_bwd(ptr(dy), ptr(y), ptr(out), LL(y.numel()), cur_stream()), 'las_tanh_bwd')
-    return out
+    return (out, None) if want_twin else out
 
 
 def infer_lengths(x):
@@ -295,44 +370,57 @@ def count_nonzero(y):
 
 # ----------------------------------------------------------------------------- Linear (+tanh)
 class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) on the last dim; act in {0: none, 1: tanh}.  reference asr.py:307,316 / :46,69 / :384,419."""
+    """y = act(x W^T + b) on the last dim; act in {0: none, 1: tanh}.  reference asr.py:307,316 / :46,69 / :384,419.
+    bf16 mode: the GEMMs read the bf16 twins of x (attached by its producer) and W (the optimiser's shadow) when there
+    are any, and the forward GEMM's epilogue writes y's twin for the next consumer."""
+    last_twin = None
 
     @staticmethod
     def forward(ctx, x, w, b, act):
+        x16 = twin(x)
         x = x.contiguous()
         x2 = x.view(-1, x.shape[-1])
-        y = gemm(x2, w, transB=True, bias=b, act=act)
+        x16 = x16.reshape(-1, x.shape[-1]) if x16 is not None and x16.is_contiguous() else twin(x2, make=True)
+        w16 = twin(w)
+        M, N = x2.shape[0], w.shape[0]
+        y16 = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if twins_on() and M * N >= TWIN_MIN_ELEMS and N % 8 == 0 else None
+        y = gemm(x2, w, transB=True, bias=b, act=act, A16=x16, B16=w16, C16=y16)
         ctx.save_for_backward(x2, w, y if act else None)
-        ctx.act, ctx.has_b, ctx.xshape, ctx.bias = act, b is not None, x.shape, b
-        return y.view(*x.shape[:-1], w.shape[0])
+        ctx.act, ctx.has_b, ctx.xshape, ctx.bias, ctx.x16, ctx.w16 = act, b is not None, x.shape, b, x16, w16
+        LinearFn.last_twin = y16.view(*x.shape[:-1], N) if y16 is not None else None
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, gy):
         x2, w, y = ctx.saved_tensors
+        x16, w16 = ctx.x16, ctx.w16
         gy = gy.contiguous().view(-1, w.shape[0])
         if ctx.act:
-            gy = tanh_bwd(gy, y)
+            gy, gy16 = tanh_bwd(gy, y, want_twin=True)
+        else:
+            gy16 = twin(gy, make=True)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gemm(gy, w).view(ctx.xshape)                       # [M,N]x[N,K]
+            gx = gemm(gy, w, A16=gy16, B16=w16).view(ctx.xshape)    # [M,N]x[N,K]
         b = ctx.bias
         tw, tb = wgrad_target(w), (wgrad_target(b) if b is not None else None)
         if ctx.needs_input_grad[1] and tw is not None and (not ctx.has_b or tb is not None):
             def side():
-                gemm(gy, x2, tw, transA=True, beta=1.0)             # accumulate into the flat gradient buffer
+                gemm(gy, x2, tw, transA=True, beta=1.0, A16=gy16, B16=x16)      # accumulate into the flat gradient buffer
                 if ctx.has_b:
                     colsum(gy, tb, beta=1.0)
-            on_side_stream(side, [gy, x2])
+            on_side_stream(side, [gy, x2, gy16, x16])
             return gx, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = gemm(gy, x2, transA=True)                          # [N,M]x[M,K]
+            gw = gemm(gy, x2, transA=True, A16=gy16, B16=x16)       # [N,M]x[M,K]
         if ctx.has_b and ctx.needs_input_grad[2]:
             gb = colsum(gy, torch.empty(w.shape[0], dtype=torch.float32, device=w.device))
         return gx, gw, gb, None
 
 
 def linear(x, w, b=None, act=0):
-    return LinearFn.apply(x, w, b, act)
+    y = LinearFn.apply(x, w, b, act)
+    return with_twin(y, LinearFn.last_twin)
 
 
 # ----------------------------------------------------------------------------- persistent (Bi)LSTM layer
@@ -344,13 +432,15 @@ def lstm_out_shape(T, H, ND, sr, concat):
     return (T + sr - 1) // sr, ND * H
 
 
-def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
+def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     L_ = _lib.lib()
+    x16 = twin(x)
     x = x.contiguous()
     T, B, Iin = x.shape
     ND, H4, H = w_hh.shape
     dev = x.device
-    xproj = gemm(x.view(T * B, Iin), w_ih, transB=True)
+    x16 = x16.reshape(T * B, Iin) if x16 is not None and x16.is_contiguous() else twin(x.view(T * B, Iin), make=True)
+    xproj = gemm(x.view(T * B, Iin), w_ih, transB=True, A16=x16, B16=w_ih16 if twins_on() else None)
     T_out, F_out = lstm_out_shape(T, H, ND, sr, concat)
     hf = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
@@ -364,7 +454,7 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
                                   I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
                                   ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
-    return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec)
+    return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec, x16, w_ih16 if twins_on() else None)
 
 
 def _lstm_bwd(saved, gy, need_gx, targets=None):
@@ -372,7 +462,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     targets = (gw_ih, gw_hh, gb_ih, gb_hh) gradient buffers to accumulate into on the side stream (returns None
     for the weight gradients then)."""
     L_ = _lib.lib()
-    x, lens, w_ih, w_hh, hf, gates, cs, status, sr, concat, prec = saved
+    x, lens, w_ih, w_hh, hf, gates, cs, status, sr, concat, prec, x16, w_ih16 = saved
     T, B, Iin = x.shape
     ND, H4, H = w_hh.shape
     dev = x.device
@@ -387,27 +477,32 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
               'las_lstm_rec_bwd')
     x2 = x.view(T * B, Iin)
     hf2 = hf.view(T * B, ND * H)
+    # bf16 twins of the GEMM operands of this layer's backward (one cast pass each: 6 bytes per element, HBM-bound; the
+    # three GEMMs that read d gates then move half the bytes and convert nothing while staging)
+    dgf16 = twin(dgf, make=True)
+    hf16 = twin(hf2, make=True) if dgf16 is not None else None
 
     def wgrads(gw_ih, gw_hh, gb_ih, gb_hh, beta):
-        gemm(dgf, x2, gw_ih, transA=True, beta=beta)                            # [ND*4H, I]
+        gemm(dgf, x2, gw_ih, transA=True, beta=beta, A16=dgf16, B16=x16)        # [ND*4H, I]
         colsum(dgf, gb_ih, beta=beta)
         if gb_hh is not None:
             colsum(dgf, gb_hh, beta=beta)
         for d in range(ND):
             if T > 1:
                 if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
-                    A, Bm = dgf[B:, d * H4:(d + 1) * H4], hf2[:(T - 1) * B, d * H:(d + 1) * H]
+                    sa, sb = (slice(B, None), slice(d * H4, (d + 1) * H4)), (slice(0, (T - 1) * B), slice(d * H, (d + 1) * H))
                 else:           # sum_{t<=T-2} dg[t]^T h[t+1]
-                    A, Bm = dgf[:(T - 1) * B, d * H4:(d + 1) * H4], hf2[B:, d * H:(d + 1) * H]
-                gemm(A, Bm, gw_hh[d], transA=True, beta=beta)
+                    sa, sb = (slice(0, (T - 1) * B), slice(d * H4, (d + 1) * H4)), (slice(B, None), slice(d * H, (d + 1) * H))
+                two = dgf16 is not None and hf16 is not None
+                gemm(dgf[sa], hf2[sb], gw_hh[d], transA=True, beta=beta, A16=dgf16[sa] if two else None, B16=hf16[sb] if two else None)
             elif beta == 0.0:
                 gw_hh[d].zero_()
 
     if targets is not None:
-        on_side_stream(lambda: wgrads(targets[0], targets[1], targets[2], targets[3], 1.0), [dgf, x, hf])
-        gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
+        on_side_stream(lambda: wgrads(targets[0], targets[1], targets[2], targets[3], 1.0), [dgf, x, hf, dgf16, hf16, x16])
+        gx = gemm(dgf, w_ih, A16=dgf16, B16=w_ih16).view(T, B, Iin) if need_gx else None
         return gx, None, None, None
-    gx = gemm(dgf, w_ih).view(T, B, Iin) if need_gx else None
+    gx = gemm(dgf, w_ih, A16=dgf16, B16=w_ih16).view(T, B, Iin) if need_gx else None
     gw_ih = torch.empty(ND * H4, Iin, dtype=torch.float32, device=dev)
     gw_hh = torch.empty_like(w_hh)
     gb = torch.empty(ND * H4, dtype=torch.float32, device=dev)
@@ -442,8 +537,8 @@ class _LstmLeavesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, lens, sr, concat, status, cats, cat_grads, *leaves):
-        w_ih, w_hh, b_ih, b_hh = cats
-        y, ctx.saved = _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status)
+        w_ih, w_hh, b_ih, b_hh = cats[:4]
+        y, ctx.saved = _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=cats[4] if len(cats) > 4 else None)
         ctx.shapes = [tuple(l.shape) for l in leaves]
         ctx.cat_grads = cat_grads if _SIDE['enabled'] else None
         return y
@@ -469,7 +564,9 @@ class _LstmLeavesFn(torch.autograd.Function):
 
 
 def lstm_layer_leaves(x, lens, cats, sr, concat, status, ND, leaves, cat_grads=None):
-    return _LstmLeavesFn.apply(x, lens, sr, concat, status, cats, cat_grads, *leaves)
+    """cats = (w_ih, w_hh, b_ih, b_hh[, w_ih bf16 shadow]) kernel-facing concatenated views."""
+    y = _LstmLeavesFn.apply(x, lens, sr, concat, status, cats, cat_grads, *leaves)
+    return with_twin(y, twin(y, make=True))          # operand of the layer's projection GEMM
 
 
 # ----------------------------------------------------------------------------- joint loss

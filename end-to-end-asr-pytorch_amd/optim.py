@@ -25,6 +25,7 @@ class FlatOptimizer:
         self.norm3 = torch.zeros(3, dtype=torch.float32, device=dev)   # grad norm, clip coef, skip flag
         self.ws = torch.empty(_lib.lib().las_grad_norm_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.world_size = world_size
+        self.p16 = getattr(model, 'flat_params16', None)      # bf16 shadow of the weights, rewritten by the update kernels
 
     def zero_grad(self):
         self.g.zero_()
@@ -39,11 +40,15 @@ class FlatOptimizer:
                                ptr(self.step_dev), cur_stream()), 'las_grad_norm')
         if self.type == 'Adam':
             check(L_.las_adam_step(ptr(self.p), ptr(self.g), ptr(self.s1), ptr(self.s2), LL(n), F(self.lr), F(0.9), F(0.999),
-                                   F(self.eps), ptr(self.norm3), ptr(self.step_dev), I(int(zero_grad)), cur_stream()),
+                                   F(self.eps), ptr(self.norm3), ptr(self.step_dev), I(int(zero_grad)), self._p16(), cur_stream()),
                   'las_adam_step')
         else:
             check(L_.las_adadelta_step(ptr(self.p), ptr(self.g), ptr(self.s1), ptr(self.s2), LL(n), F(self.lr), F(0.9),
-                                       F(self.eps), ptr(self.norm3), I(int(zero_grad)), cur_stream()), 'las_adadelta_step')
+                                       F(self.eps), ptr(self.norm3), I(int(zero_grad)), self._p16(), cur_stream()), 'las_adadelta_step')
+
+    def _p16(self):
+        from ._lib import P
+        return P(self.p16.data_ptr()) if self.p16 is not None and self.p16.is_cuda else None
 
     def state_dict(self):
         return dict(type=self.type, lr=self.lr, s1=self.s1, s2=self.s2, step=self.step_dev)

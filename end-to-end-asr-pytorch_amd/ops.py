@@ -1,4 +1,6 @@
 """torch.autograd.Function wrappers over the C ABI (PyTorch here = device memory + streams only)."""
+import os
+
 import torch
 
 from . import _lib
@@ -253,7 +255,7 @@ def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=Non
     return C
 
 
-USE_BF16_TWINS = True       # (tests / A-B measurements switch the bf16 operand twins off)
+USE_BF16_TWINS = not os.environ.get('LAS_NO_BF16_TWINS')      # (tests / A-B measurements switch the bf16 operand twins off)
 TWIN_MIN_ELEMS = 1 << 18    # below this an operand is not worth a cast pass: the GEMM converts it while staging
 
 

@@ -106,6 +106,10 @@ def attach_pmc_traffic(roof, workload):
     if not os.path.exists(path):
         return
     pmc = json.load(open(path))
+    meta = pmc.pop('_meta', {})
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from pmc_summary import kernel_sources_sha
+    stale = meta.get('kernel_sources_sha') != kernel_sources_sha()     # counters were taken on other kernel sources
     for row in [roof] + roof.get('breakdown', []):
         if not row.get('single_kernel'):
             continue
@@ -114,6 +118,7 @@ def attach_pmc_traffic(roof, workload):
             n = sum(h['launches'] for h in hits)
             row['traffic'] = sum(h['hbm_MB_per_launch_corrected'] * h['launches'] for h in hits) / n * 1e6
             row['traffic_unit'] = 'B/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes, ' + os.path.basename(path) + ')'
+            row['traffic_stale'] = stale
 
 
 def note(msg):

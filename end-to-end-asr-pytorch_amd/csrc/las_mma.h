@@ -47,7 +47,7 @@ __device__ __forceinline__ void mma_rows(f32x4 (&acc)[NB], const typename CT<PRE
 // tanh through one v_exp: |abs err| ~1e-7, used where the argument is already O(1) noise-limited.
 __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(2.f * x);
-    return 1.f - __fdividef(2.f, e + 1.f);        // v_rcp + v_mul: the IEEE division here was 12 instructions per tanh
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);      // v_rcp (1 ulp) + v_mul: a division, __fdividef included, is 7-12 instructions here
 }
 
 // Cell pointwise backward of the EARLIER decode step, fused into the skinny product that yields its recurrent dh
@@ -59,7 +59,7 @@ struct las_skinny_pw {
     float* dgates;                        // [B][4C] out
 };
 
-__device__ __forceinline__ float fast_sig(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_sig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 int las_skinny_launch_pk(int prec, const float* x0, long ldx0, const float* w0, long ldw0, int K0, const float* x1,
                          long ldx1, const float* w1, long ldw1, int K1, const float* x2, long ldx2, const float* w2,

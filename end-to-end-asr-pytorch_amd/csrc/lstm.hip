@@ -22,6 +22,7 @@
 //     enforced by the LDS request.  Spins are bounded; a timeout sets *status and every workgroup exits.
 //   * the published history doubles as the saved activations for BPTT.
 // Backward mirrors this with dgates[B,4H] as the exchanged quantity and W_hh^T columns resident.
+#include <type_traits>
 #include "las_mma.h"
 #include <stdlib.h>
 
@@ -48,8 +49,10 @@ struct SyncWords {          // zeroed by hipMemsetAsync before every launch
 };
 
 // one-v_exp activations for the cell pointwise (abs err ~1e-7; the recurrence is fp32 throughout)
-__device__ __forceinline__ float fsig(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) { return 1.f - __fdividef(2.f, __expf(2.f * x) + 1.f); }
+// (v_rcp_f32, 1 ulp: __fdividef compiles to the full IEEE division sequence -- v_div_scale, v_rcp, four FMAs, v_div_fmas,
+// v_div_fixup -- on this toolchain)
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // One lane polls `cnt >= target` (sc1 loads); returns false on timeout / abort.
 __device__ __forceinline__ bool wait_counter(unsigned* cnt, unsigned target, unsigned* abort_word) {
@@ -478,6 +481,342 @@ __global__ __launch_bounds__(KS > 16 ? NT : NT + 64) void lstm_fwd_kernel(LstmAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, tagged granules
+// The same recurrence with a hand-off that has NO flag, NO drain and ONE workgroup barrier per step (bf16, weights in
+// registers).  Differences from lstm_fwd_kernel:
+//   * MFMA roles are swapped: A = the wave's 16 weight rows ordered (unit, gate) -- wave w owns units 4w .. 4w+3 of the
+//     workgroup's 16 --, B = the h tile.  Lane (fr, fq) then receives acc[0..3] = the i, f, g, o pre-activations of unit
+//     4w + fq for batch row fr: the cell update runs on the accumulators, no trip through LDS, no barrier.
+//   * h_t leaves as self-validating 16-byte granules {6 batch rows of ONE unit as bf16, tag = step + 1} written by one
+//     lane with one store (the six rows are gathered over DPP row shifts); the ring of four steps is zeroed before the
+//     launch, so a tag can only be matched by this launch's store of that step.  A consumer sweeps its share of the
+//     H * ceil(Bs / 6) granules (consecutive lanes <-> consecutive granules) until every tag matches, writes the rows into
+//     the h tile in LDS (double-buffered: the one barrier per step separates a tile's writers from its readers) and goes
+//     on.  MI355X_MICROARCH.md "R2": a naturally aligned 16-byte store is observed untorn by 16-byte sc1 loads on gfx950
+//     (not an architectural guarantee); against the flag form it saves the vmcnt(0) drain, the signal store, the poll's
+//     round trip and three barriers (handoff-1to1 vs handoff-flag rows of the guide's price table).
+//   * In steady state the FIRST pass of a sweep matches (cycle stamps: 1.00-1.03 passes per step): a step pays one L2
+//     round trip for the hand-off.  (Several passes in flight were tried; the compiler's register renaming of the
+//     re-issued loads forces a full wait per iteration, and there is nothing left for them to win.)
+//   * The four compute waves touch global memory ONLY for the hand-off.  A wave's vector-memory operations complete in
+//     order, so x-projection loads (HBM) and the saved-activation stores in front of a sweep delayed it: 1.85 us per step
+//     with them, 1.57 without the stores, 1.45 without both (H = 320, B = 24).  A fifth wave does that I/O: it loads the
+//     x-projection rows three steps ahead and hands them over in LDS, and stores h / y / gates / c of the step before
+//     from LDS; the barrier of the step is its only synchronisation with the compute waves.
+__device__ __forceinline__ int gr_chunks(int rows) { return (rows >> 4) * 3 + ((rows & 15) + 5) / 6; }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// One poll of a granule: an sc1 (L1-bypassing) 16-byte load the compiler can neither merge with an identical poll nor
+// hoist out of the polling loop (its offset passes through an empty volatile asm), but still counts in vmcnt.
+__device__ __forceinline__ u32x4 gr_poll(__amdgpu_buffer_rsrc_t rs, int off) {
+    asm volatile("" : "+v"(off));
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+}
+#ifdef LAS_PK_STAMPS            // diagnostic build only (make stamps): cycle sums per phase of a step, printed by workgroup 0
+#define GR_ST_DECL unsigned gst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_last = (unsigned)__builtin_amdgcn_s_memtime()
+#define GR_ST(i) do { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); gst[i] += now_ - gst_last; gst_last = now_; } while (0)
+#define GR_ST_PRINT(T) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) printf("gr stamps wave %d T=%d: sweep %u barrier %u mfma %u cell %u passes %u\n", (int)(threadIdx.x >> 6), T, gst[0] / T, gst[1] / T, gst[2] / T, gst[3] / T, gst[4]); } while (0)
+#else
+#define GR_ST_DECL
+#define GR_ST(i)
+#define GR_ST_PRINT(T)
+#endif
+constexpr int GR_XLD = 16 * 4 + 4;        // floats per batch row of the x-projection / gate tiles in LDS: [16 units][4 gates] + pad
+constexpr int GR_HLD = 16 * 2 + 2;        // ... of the {h, c} tile
+
+template <int NB, int KS>
+__global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const float* __restrict__ xproj,
+                                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                      const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
+                                                      float* __restrict__ y, float* __restrict__ hf,
+                                                      u32x4* __restrict__ ring, float* __restrict__ gates,
+                                                      float* __restrict__ cs, SyncWords* sync, int* status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, B = a.B, ND = a.ND;
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    const Role role = lstm_role(a);
+    if (role.idle) return;
+    const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
+    const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
+    bf16_t* Hl = (bf16_t*)smem;                         // [2][NB*16][ld]; pad rows / columns stay zero
+    float* Xl = (float*)(Hl + 2 * NB * 16 * ld);        // [2][NB*16][GR_XLD]  x-projection of the step (I/O wave -> compute)
+    float* Sg = Xl + 2 * NB * 16 * GR_XLD;              // [2][NB*16][GR_XLD]  post-activation gates (compute -> I/O wave)
+    float* Sh = Sg + 2 * NB * 16 * GR_XLD;              // [2][NB*16][GR_HLD]  {h, c}
+    int* lensl = (int*)(Sh + 2 * NB * 16 * GR_HLD);     // [NB*16]
+    int* flag = lensl + NB * 16;
+    const bool io = threadIdx.x >= NT;                  // the fifth wave
+    if (!io) {
+        for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) ((unsigned*)Hl)[i] = 0u;      // 2 tiles of bf16 = NB*16*ld words
+        for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
+    }
+    __syncthreads();
+    unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
+    const int gl = group_local(a, cnt, &sync->abort_, flag);       // only decides the store flavour here
+    if (gl < 0) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+    const bool local = gl == 1;
+    const int ND4H = ND * 4 * H;
+    const int lane = threadIdx.x & 63;
+    if (io) {
+        // ---- I/O wave.  Item = 4 consecutive units of one (batch row, gate): lane + 64 q -> row = item / 16,
+        // gate = (item / 4) % 4, quarter = item % 4; 16-byte buffer accesses (H % 4 == 0), masked lanes use an
+        // out-of-range offset instead of a branch, so the wave's code is straight-line and its waits are exact counts.
+        constexpr int NQ = NB * 4;
+        constexpr int OOB = 0x7ffffff0;
+        const long nrow = (long)a.T * B;
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gates, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hf, 0, (int)(nrow * ND * H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * ND * H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
+        auto tstep = [&](int s) { const int sc = min(s, a.T - 1); return d == 0 ? sc : a.T - 1 - sc; };
+        auto xload = [&](int s, u32x4 (&xr)[NQ]) {
+            const int t = tstep(s);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                const int off = (row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * 4 * H + gi * H + j0 + u0) * 4) : OOB;
+                xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            }
+        };
+        auto xstore = [&](int s, const u32x4 (&xr)[NQ]) {
+            unsigned* xl = (unsigned*)Xl + (s & 1) * NB * 16 * GR_XLD;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                unsigned* p = xl + row * GR_XLD + u0 * 4 + gi;
+                p[0] = xr[q][0]; p[4] = xr[q][1]; p[8] = xr[q][2]; p[12] = xr[q][3];
+            }
+        };
+        auto sflush = [&](int s, bool valid) {           // saved activations of step s: LDS -> global (non-temporal)
+            const int t = tstep(s);
+            const unsigned* sg = (const unsigned*)Sg + (s & 1) * NB * 16 * GR_XLD;
+            const unsigned* sh = (const unsigned*)Sh + (s & 1) * NB * 16 * GR_HLD;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                const unsigned* p = sg + row * GR_XLD + u0 * 4 + gi;
+                const u32x4 v = {p[0], p[4], p[8], p[12]};
+                const int off = (valid && row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * 4 * H + gi * H + j0 + u0) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rg, off, 0, 2);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int it = lane + 64 * q, row = it >> 2, u0 = (it & 3) * 4;
+                const unsigned* p = sh + row * GR_HLD + u0 * 2;
+                const u32x4 hv4 = {p[0], p[2], p[4], p[6]}, cv4 = {p[1], p[3], p[5], p[7]};
+                const bool ok = valid && row < Bl && j0 + u0 < H;
+                const int b = b0 + row;
+                const int off = ok ? (int)((((long)t * B + b) * (ND * H) + d * H + j0 + u0) * 4) : OOB;
+                bool yok = false;
+                const long yo = y_offset(a, t, b, d, j0 + u0, yok);
+                const int offy = (ok && yok && !a.y_is_hf) ? (int)(yo * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(hv4, rh, off, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(cv4, rc, off, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(hv4, ry, offy, 0, 2);
+            }
+        };
+        u32x4 x0[NQ], x1[NQ], x2[NQ];                    // three sets: a value is used three phases after its request
+        xload(0, x0); xload(1, x1); xload(2, x2);
+        xstore(0, x0); xload(3, x0);
+        __syncthreads();                                 // barrier(0)
+        // phase s (between barrier(s) and barrier(s+1)): hand over step s+1's x-projection, request step s+4's, store step
+        // s-1.  (The only back edge follows the third phase, so the compiler's wait counts at the loop head stay exact.)
+        for (int s = 0;; s += 3) {
+            xstore(s + 1, x1); xload(s + 4, x1);
+            sflush(max(s - 1, 0), s > 0);
+            __syncthreads();
+            if (s + 1 >= a.T) break;
+            xstore(s + 2, x2); xload(s + 5, x2);
+            sflush(s, true);
+            __syncthreads();
+            if (s + 2 >= a.T) break;
+            xstore(s + 3, x0); xload(s + 6, x0);
+            sflush(s + 1, true);
+            __syncthreads();
+            if (s + 3 >= a.T) break;
+        }
+        sflush(a.T - 1, true);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    // A operand: row fr of the wave's tile = (unit 4 wave + fr / 4, gate fr % 4); lane holds k = 32 ks + 8 fq + {0..7}
+    bf16x8 wfrag[KS];
+    {
+        const int jw = j0 + 4 * wave + (fr >> 2), gi = fr & 3;
+        const bool rowok = jw < H;
+        const float* wrow = w_hh + ((long)d * 4 * H + gi * H + min(jw, H - 1)) * H;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = ks * 32 + fq * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wrow[min(c + e, H - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (rowok && c + e < H) ? v[e] : 0.f;
+            const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            wfrag[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    // my cell elements: unit je (ul within the workgroup), batch rows bt * 16 + fr
+    const int ul = 4 * wave + fq, je = j0 + ul;
+    const bool evu = je < H;
+    float c_state[NB];
+    f32x4 bias;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) bias[gi] = evu ? b_ih[d * 4 * H + gi * H + je] + b_hh[d * 4 * H + gi * H + je] : 0.f;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) c_state[bt] = 0.f;
+    const int nck = gr_chunks(a.Bs), nckl = gr_chunks(Bl), total = H * nckl;
+    const long slot_stride = (long)a.NS * H * nck;                      // granules per ring slot of one direction
+    u32x4* ringg = ring + (long)d * HX_SLOTS * slot_stride + (long)bs * H * nck;
+    const int cc = fr >= 12 ? 2 : fr >= 6 ? 1 : 0;
+    const bool writer = evu && fr == cc * 6;
+    // my share of the sweep: the workgroup's H * nckl granules in four contiguous quarters, one per wave (equal work, and a
+    // wave instruction reads consecutive granules); slot u of lane l is granule wave * Q + 64 u + l.  Offsets in the ring
+    // slot, destinations in the h tile and the spare-row flags are the same every step.
+    constexpr int SWMAX = 4;                             // host side: H * chunks(Bs) <= 4 * 256
+    const int Q = (total + 3) / 4;
+    const int nsw = (Q + 63) / 64;
+    int g_off[SWMAX], g_dst[SWMAX];
+    bool g_six[SWMAX];
+#pragma unroll
+    for (int u = 0; u < SWMAX; ++u) {
+        const int idx = lane + 64 * u, i = wave * Q + idx;
+        const bool ok = idx < Q && i < total;
+        const int j = ok ? i / nckl : 0, ch = ok ? i - j * nckl : 0, bt = ch / 3, c3 = ch - bt * 3;
+        g_off[u] = ok ? (j * nck + ch) * 16 : 0x7ffffff0;
+        g_dst[u] = ok ? (bt * 16 + c3 * 6) * ld + j : -1;
+        g_six[u] = c3 < 2;
+    }
+
+    GR_ST_DECL;
+    for (int s = 0; s < a.T; ++s) {
+        const int t = d == 0 ? s : a.T - 1 - s;
+        bf16_t* buf = Hl + (s & 1) * NB * 16 * ld;
+        if (s > 0) {
+            // ---- sweep: the granules of step s-1, until every tag reads s.  Branch-free: a granule that has matched is
+            // re-requested at an out-of-range offset (returns zeros without memory traffic), the loop is uniform over the wave.
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ringg + ((s - 1) & (HX_SLOTS - 1)) * slot_stride), 0,
+                                                                          H * nck * 16, 0x00020000);
+            auto sweep = [&](auto swc) -> bool {
+                constexpr int SW = decltype(swc)::value;
+                constexpr int OOB = 0x7ffffff0;
+                u32x4 v[SW], got[SW];
+                int off[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) {
+                    off[u] = g_off[u];
+                    got[u] = (u32x4){0u, 0u, 0u, 0u};
+                    v[u] = gr_poll(rs, off[u]);
+                }
+                unsigned spins = 0;
+                while (true) {
+                    bool need = false;
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) {
+                        const bool hit = off[u] != OOB && v[u][3] == (unsigned)s;
+                        off[u] = hit ? OOB : off[u];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) got[u][e] = hit ? v[u][e] : got[u][e];
+                        need = need || off[u] != OOB;
+                    }
+#ifdef LAS_PK_STAMPS
+                    ++gst[4];
+#endif
+                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) v[u] = gr_poll(rs, off[u]);
+                    if ((++spins & 255u) == 0) {
+                        if (__hip_atomic_load(&sync->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > SPIN_LIMIT) {
+                            __hip_atomic_store(&sync->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *status = LAS_E_TIMEOUT;
+                            return false;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SW; ++u) {
+                    if (g_dst[u] < 0) continue;
+                    bf16_t* dst = buf + g_dst[u];
+                    dst[0] = (bf16_t)(got[u][0] & 0xffffu); dst[ld] = (bf16_t)(got[u][0] >> 16);
+                    dst[2 * ld] = (bf16_t)(got[u][1] & 0xffffu); dst[3 * ld] = (bf16_t)(got[u][1] >> 16);
+                    if (g_six[u]) { dst[4 * ld] = (bf16_t)(got[u][2] & 0xffffu); dst[5 * ld] = (bf16_t)(got[u][2] >> 16); }
+                }
+                return true;
+            };
+            const bool ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
+                           : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            if (!ok_) return;
+        }
+        GR_ST(0);
+        __syncthreads();                                 // barrier(s): h tile complete, x-projection of step s in Xl
+GR_ST(1);
+        // ---- gate pre-activations of my four units: x-projection + bias + W_hh h_{t-1}
+        f32x4 acc[NB], acc2[NB];
+        const float* xl = Xl + (s & 1) * NB * 16 * GR_XLD;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            acc[bt] = *(const f32x4*)(xl + (bt * 16 + fr) * GR_XLD + ul * 4) + bias;
+            acc2[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (s > 0) {
+            constexpr int CH = KS <= 10 ? KS : 8;
+#pragma unroll
+            for (int k0 = 0; k0 < KS; k0 += CH) {
+                bf16x8 hv_[CH][NB];
+#pragma unroll
+                for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt)
+                        hv_[ks][bt] = *(const bf16x8*)(buf + (bt * 16 + fr) * ld + min((k0 + ks) * 32, Kp - 32) + fq * 8);
+#pragma unroll
+                for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) {
+                        if (ks & 1) acc2[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[k0 + ks], hv_[ks][bt], acc2[bt], 0, 0, 0);
+                        else acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[k0 + ks], hv_[ks][bt], acc[bt], 0, 0, 0);
+                    }
+            }
+        }
+#ifdef LAS_PK_STAMPS
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc2[0][0]));
+#endif
+        GR_ST(2);
+        // ---- cell update on the accumulators; publish h_t, then leave the saved activations to the I/O wave
+        u32x4* slot = ringg + (s & (HX_SLOTS - 1)) * slot_stride;
+        float* sg = Sg + (s & 1) * NB * 16 * GR_XLD;
+        float* sh = Sh + (s & 1) * NB * 16 * GR_HLD;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const int row = bt * 16 + fr;
+            const bool mq = evu && row < Bl && t < lensl[row];
+            const f32x4 pre = acc[bt] + acc2[bt];
+            const float ig = fsig(pre[0]), fg = fsig(pre[1]), gg = ftanh(pre[2]), og = fsig(pre[3]);
+            const float cn = fg * c_state[bt] + ig * gg;
+            const float hn = og * ftanh(cn);
+            c_state[bt] = mq ? cn : c_state[bt];
+            const float hv = mq ? hn : 0.f;
+            const float hnext = las_dpp<0x101, 0xf>(0.f, hv);                      // row_shl:1 -> batch row fr + 1
+            const unsigned p0 = pack_bf16x2(hv, hnext), p1 = dpp_u<0x102>(p0), p2 = dpp_u<0x104>(p0);
+            {
+                // (one rsrc per workgroup, the granule's place as a per-lane offset: a per-lane rsrc costs a waterfall loop)
+                const u32x4 gr = {p0, p1, p2, (unsigned)s + 1u};
+                __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)slot, 0, H * nck * 16, 0x00020000);
+                const int woff = (writer && row < Bl) ? je * nck * 16 + (bt * 3 + cc) * 16 : 0x7ffffff0;
+                if (local) __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 16);
+            }
+            *(f32x4*)(sg + row * GR_XLD + ul * 4) = mq ? (f32x4){ig, fg, gg, og} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            *(float2*)(sh + row * GR_HLD + ul * 2) = make_float2(hv, mq ? c_state[bt] : 0.f);
+        }
+        GR_ST(3);
+    }
+    GR_ST_PRINT(a.T);
+    __syncthreads();                                     // barrier(T): the I/O wave stores the last step
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // dh_rec[b][j] = sum_m dgates_next[b][m] * W_hh[m][j]; K = 4H is walked in NC chunks so the pulled
 // dgates tile fits in LDS for large H; wave w takes a quarter of each chunk's k-steps.
@@ -904,6 +1243,289 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, K-split, tagged granules
+// lstm_bwd_ks_kernel's reduce-scatter with the hand-off of lstm_fwd_gr_kernel (bf16): a producer's 16-column piece for
+// consumer c leaves as 16-byte granules {4 consecutive columns of one batch row as bf16, tag = step + 1, 0} -- what a lane
+// holds after the transposed MFMA -- into c's inbox [producer][row][4]; the consumer sweeps its G * Bl * 4 granules until
+// every tag matches, spreads them as f32 into LDS [row][column][producer], and after the barrier the cell lane of
+// (row, unit) adds its G partial sums with 16-byte LDS reads.  No flag, no drain; two barriers per step (sums complete,
+// dgates tile complete).  The compute waves touch global memory only for the hand-off: a fifth wave loads gates / c /
+// c_prev / dy three steps ahead into LDS and stores d gates (the weight-gradient GEMMs' operand) from LDS.
+constexpr int BG_CLD = 16 * 4 + 4;                       // floats per batch row of the {c, c_prev, dy, -} tile
+template <int NB, int MT>
+__global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const float* __restrict__ dy,
+                                                         const float* __restrict__ gates, const float* __restrict__ cs,
+                                                         const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
+                                                         u32x4* __restrict__ ring, float* __restrict__ dgf,
+                                                         SyncWords* sync, int* status) {
+    constexpr int LDK = 64 + 8;                           // own dgates tile: k = gate * 16 + unit
+    constexpr int OOB = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, B = a.B, ND = a.ND, K4 = 4 * H, G = a.G;
+    const Role role = lstm_role(a);
+    if (role.idle) return;
+    const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
+    const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
+    const int PS = (G + 3) & ~3, RLD = 16 * PS + 4;       // partial sums [row][column][producer], rows padded (banks)
+    bf16_t* Dl = (bf16_t*)smem;                           // [NB*16][LDK]        my dgates of this step (MFMA B operand)
+    float* Red = (float*)(Dl + NB * 16 * LDK);            // [NB*16][RLD]
+    float* Gi = Red + NB * 16 * RLD;                      // [2][NB*16][GR_XLD]  saved gates of the step   (I/O wave -> compute)
+    float* Ci = Gi + 2 * NB * 16 * GR_XLD;                // [2][NB*16][BG_CLD]  {c, c_prev, dy, -}
+    float* Do = Ci + 2 * NB * 16 * BG_CLD;                // [2][NB*16][GR_XLD]  d gates in f32            (compute -> I/O wave)
+    int* lensl = (int*)(Do + 2 * NB * 16 * GR_XLD);
+    int* flag = lensl + NB * 16;
+    const bool io = threadIdx.x >= NT;
+    if (!io) {
+        for (int i = threadIdx.x; i < NB * 16 * LDK / 2; i += NT) ((unsigned*)Dl)[i] = 0u;
+        for (int i = threadIdx.x; i < NB * 16 * RLD; i += NT) Red[i] = 0.f;
+        for (int i = threadIdx.x; i < NB * 16; i += NT) lensl[i] = i < Bl ? lens[b0 + i] : 0;
+    }
+    __syncthreads();
+    unsigned* cnt = &sync->cnt[(d * MAX_SLICES + bs) * CNT_STRIDE];
+    const int gl = group_local(a, cnt, &sync->abort_, flag);
+    if (gl < 0) { if (threadIdx.x == 0) *status = LAS_E_TIMEOUT; return; }
+    const bool local = gl == 1;
+    const int ND4H = ND * K4, NDH = ND * H;
+    const int lane = threadIdx.x & 63;
+    auto tstep = [&](int s) { const int sc = min(s, a.T - 1); return d == 0 ? a.T - 1 - sc : sc; };   // reverse of the forward order
+    if (io) {
+        // ---- I/O wave (see lstm_fwd_gr_kernel): item = 4 consecutive units of one (batch row[, gate])
+        constexpr int NQ = NB * 4;
+        const long nrow = (long)a.T * B;
+        __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gates, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * NDH * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc((void*)dgf, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        struct In { u32x4 g4[NQ], c[NB], cp[NB], y[NB]; };
+        auto xload = [&](int s, In& x) {
+            const int t = tstep(s), tp = d == 0 ? t - 1 : t + 1;
+            const bool sv = s < a.T;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                const bool ok = sv && row < Bl && j0 + u0 < H && t < lensl[min(row, NB * 16 - 1)];
+                x.g4[q] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? (int)((((long)t * B + b0 + row) * ND4H + d * K4 + gi * H + j0 + u0) * 4) : OOB, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int it = lane + 64 * q, row = it >> 2, u0 = (it & 3) * 4, len = lensl[min(row, NB * 16 - 1)], b = b0 + row;
+                const bool ok = sv && row < Bl && j0 + u0 < H && t < len;
+                x.c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, ok ? (int)((((long)t * B + b) * NDH + d * H + j0 + u0) * 4) : OOB, 0, 0);
+                x.cp[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, (ok && tp >= 0 && tp < len) ? (int)((((long)tp * B + b) * NDH + d * H + j0 + u0) * 4) : OOB, 0, 0);
+                bool yok = false;
+                const long yo = y_offset(a, t, min(b, B - 1), d, j0 + u0, yok);
+                x.y[q] = __builtin_amdgcn_raw_buffer_load_b128(ry, (ok && yok) ? (int)(yo * 4) : OOB, 0, 0);
+            }
+        };
+        auto xstore = [&](int s, const In& x) {
+            unsigned* gi_ = (unsigned*)Gi + (s & 1) * NB * 16 * GR_XLD;
+            unsigned* ci_ = (unsigned*)Ci + (s & 1) * NB * 16 * BG_CLD;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                unsigned* p = gi_ + row * GR_XLD + u0 * 4 + gi;
+                p[0] = x.g4[q][0]; p[4] = x.g4[q][1]; p[8] = x.g4[q][2]; p[12] = x.g4[q][3];
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int it = lane + 64 * q, row = it >> 2, u0 = (it & 3) * 4;
+                unsigned* p = ci_ + row * BG_CLD + u0 * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[4 * e + 0] = x.c[q][e]; p[4 * e + 1] = x.cp[q][e]; p[4 * e + 2] = x.y[q][e]; }
+            }
+        };
+        auto sflush = [&](int s, bool valid) {           // d gates of step s: LDS -> global
+            const int t = tstep(s);
+            const unsigned* dg = (const unsigned*)Do + (s & 1) * NB * 16 * GR_XLD;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                const unsigned* p = dg + row * GR_XLD + u0 * 4 + gi;
+                const u32x4 v = {p[0], p[4], p[8], p[12]};
+                const int off = (valid && row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * K4 + gi * H + j0 + u0) * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro_, off, 0, 0);
+            }
+        };
+        In x0, x1, x2;                                   // three sets: a value is used three phases after its request
+        xload(0, x0); xload(1, x1); xload(2, x2);
+        xstore(0, x0); xload(3, x0);
+        __syncthreads();                                 // A(0)
+        // phase s: B(s); hand over step s+1's inputs, request step s+4's, store step s's d gates; A(s+1)
+        for (int s = 0;; s += 3) {
+            __syncthreads();
+            xstore(s + 1, x1); xload(s + 4, x1); sflush(s, true);
+            if (s + 1 >= a.T) break;
+            __syncthreads();
+            __syncthreads();
+            xstore(s + 2, x2); xload(s + 5, x2); sflush(s + 1, true);
+            if (s + 2 >= a.T) break;
+            __syncthreads();
+            __syncthreads();
+            xstore(s + 3, x0); xload(s + 6, x0); sflush(s + 2, true);
+            if (s + 3 >= a.T) break;
+            __syncthreads();
+        }
+        return;
+    }
+    const int wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    // A operand (transposed product): rows = the 16 output columns of consumer c, k = my 64 gate columns; fragments of the
+    // wave's consumers c = wave, wave + 4, ... stay in registers for all T steps.  Element e of k-step ks <-> k = 32 ks +
+    // 8 fq + e = gate 2 ks + fq / 2, unit 8 (fq & 1) + e.
+    bf16x8 wfrag[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int c = min(wave + 4 * i, G - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int gi = 2 * ks + (fq >> 1), n0 = (fq & 1) * 8, col = c * 16 + fr;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w_hh[((long)d * K4 + gi * H + min(j0 + n0 + e, H - 1)) * H + min(col, H - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (col < H && j0 + n0 + e < H) ? v[e] : 0.f;
+            const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            wfrag[i][ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    // my cell elements: unit ul of the workgroup, batch rows bt * 16 + fr
+    const int ul = 4 * wave + fq;
+    const bool evu = j0 + ul < H;
+    float dc_carry[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) dc_carry[bt] = 0.f;
+    // inboxes: ring[slot][d][bs][consumer][producer][Bs][4] granules
+    const int RW = a.Bs * 4;
+    const long slot_stride = (long)ND * a.NS * G * G * RW;
+    u32x4* ringg = ring + ((long)d * a.NS + bs) * G * G * RW;
+    // my share of the sweep (see lstm_fwd_gr_kernel): granule i = (producer p, row, column group cg)
+    constexpr int SWMAX = 4;
+    const int total = G * Bl * 4, Q = (total + 3) / 4, nsw = (Q + 63) / 64;
+    int g_off[SWMAX], g_dst[SWMAX];
+#pragma unroll
+    for (int u = 0; u < SWMAX; ++u) {
+        const int idx = lane + 64 * u, i = wave * Q + idx;
+        const bool ok = idx < Q && i < total;
+        const int p = ok ? i / (Bl * 4) : 0, rem = ok ? i - p * (Bl * 4) : 0, row = rem >> 2, cg = rem & 3;
+        g_off[u] = ok ? ((g * G + p) * RW + rem) * 16 : OOB;
+        g_dst[u] = ok ? row * RLD + cg * 4 * PS + p : -1;
+    }
+
+    for (int s = 0; s < a.T; ++s) {
+        const int t = d == 0 ? a.T - 1 - s : s;
+        if (s > 0) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ringg + ((s - 1) & (KS_SLOTS - 1)) * slot_stride), 0,
+                                                                          G * G * RW * 16, 0x00020000);
+            auto sweep = [&](auto swc) -> bool {
+                constexpr int SW = decltype(swc)::value;
+                u32x4 v[SW];
+                unsigned got[SW][2];
+                int off[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) {
+                    off[u] = g_off[u];
+                    got[u][0] = got[u][1] = 0u;
+                    v[u] = gr_poll(rs, off[u]);
+                }
+                unsigned spins = 0;
+                while (true) {
+                    bool need = false;
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) {
+                        const bool hit = off[u] != OOB && v[u][2] == (unsigned)s;
+                        off[u] = hit ? OOB : off[u];
+                        got[u][0] = hit ? v[u][0] : got[u][0];
+                        got[u][1] = hit ? v[u][1] : got[u][1];
+                        need = need || off[u] != OOB;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) v[u] = gr_poll(rs, off[u]);
+                    if ((++spins & 255u) == 0) {
+                        if (__hip_atomic_load(&sync->abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > SPIN_LIMIT) {
+                            __hip_atomic_store(&sync->abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *status = LAS_E_TIMEOUT;
+                            return false;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SW; ++u) {
+                    if (g_dst[u] < 0) continue;
+                    float* dst = Red + g_dst[u];
+                    dst[0] = __uint_as_float(got[u][0] << 16); dst[PS] = __uint_as_float(got[u][0] & 0xffff0000u);
+                    dst[2 * PS] = __uint_as_float(got[u][1] << 16); dst[3 * PS] = __uint_as_float(got[u][1] & 0xffff0000u);
+                }
+                return true;
+            };
+            const bool ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
+                           : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            if (!ok_) return;
+        }
+        __syncthreads();                                 // A(s): partial sums complete, inputs of step s in Gi / Ci
+        // ---- pointwise BPTT of my elements -> my dgates of this step
+        const float* gi_ = Gi + (s & 1) * NB * 16 * GR_XLD;
+        const float* ci_ = Ci + (s & 1) * NB * 16 * BG_CLD;
+        float* do_ = Do + (s & 1) * NB * 16 * GR_XLD;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const int row = bt * 16 + fr;
+            float dh_rec = 0.f;
+            if (s > 0) {
+                f32x4 acc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* rp = Red + row * RLD + ul * PS;
+                for (int p = 0; p < PS; p += 4) acc4 += *(const f32x4*)(rp + p);
+                dh_rec = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            }
+            const f32x4 g4 = *(const f32x4*)(gi_ + row * GR_XLD + ul * 4);
+            const f32x4 c4 = *(const f32x4*)(ci_ + row * BG_CLD + ul * 4);
+            const bool mq = evu && row < Bl && t < lensl[row];
+            const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3], ct = c4[0], cp = c4[1];
+            const float dh = c4[2] + dh_rec;
+            const float tc = ftanh(ct);
+            const float dc = dh * og * (1.f - tc * tc) + dc_carry[bt];
+            const f32x4 dg = {mq ? dc * gg * ig * (1.f - ig) : 0.f, mq ? dc * cp * fg * (1.f - fg) : 0.f,
+                              mq ? dc * ig * (1.f - gg * gg) : 0.f, mq ? dh * tc * og * (1.f - og) : 0.f};
+            dc_carry[bt] = mq ? dc * fg : 0.f;
+            *(f32x4*)(do_ + row * GR_XLD + ul * 4) = dg;
+            const unsigned lo = pack_bf16x2(dg[0], dg[1]), hi = pack_bf16x2(dg[2], dg[3]);
+            bf16_t* dl = Dl + row * LDK + ul;
+            dl[0] = (bf16_t)(lo & 0xffffu); dl[16] = (bf16_t)(lo >> 16); dl[32] = (bf16_t)(hi & 0xffffu); dl[48] = (bf16_t)(hi >> 16);
+        }
+        __syncthreads();                                 // B(s): dgates tile complete, d gates of step s in Do
+        if (s + 1 < a.T) {
+            // partial dh_{t-1}[:, 16 c .. 16 c + 15] for every consumer c; wave w takes c = w, w + 4, ...
+            __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(ringg + (s & (KS_SLOTS - 1)) * slot_stride), 0,
+                                                                          G * G * RW * 16, 0x00020000);
+            bf16x8 dv[NB][2];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) dv[bt][ks] = *(const bf16x8*)(Dl + (bt * 16 + fr) * LDK + ks * 32 + fq * 8);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int c = wave + 4 * i;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][0], dv[bt][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][1], dv[bt][1], acc, 0, 0, 0);
+                    // lane: batch row bt * 16 + fr, output columns 16 c + 4 fq + {0..3}
+                    const int row = bt * 16 + fr;
+                    const u32x4 gr = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), (unsigned)s + 1u, 0u};
+                    const int woff = (c < G && row < Bl) ? ((c * G + g) * RW + row * 4 + fq) * 16 : OOB;
+                    if (local) __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 16);
+                }
+            }
+        }
+    }
+}
+size_t bwd_gr_lds(int H, int NB) {
+    const int G = (H + 15) / 16, PS = (G + 3) & ~3, RLD = 16 * PS + 4;
+    return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4);
+}
+size_t bwd_gr_ring_bytes(const LstmArgs& a) { return (size_t)16 * KS_SLOTS * a.ND * a.NS * a.G * a.G * a.Bs * 4; }
+
 size_t bwd_ks_lds(int prec, int H, int NB, bool wdirect) {
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, G = (H + 15) / 16;
     return (size_t)((wdirect ? 0 : G * 16) + NB * 16) * (64 + vec) * sz + sizeof(unsigned) * (size_t)G * ks_words_per_tile(prec, NB) +
@@ -980,6 +1602,25 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
     LAS_LAUNCH_OK();
     return LAS_OK;
 }
+size_t fwd_gr_lds(int H, int NB) {
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    return (size_t)2 * NB * 16 * ld * 2 + sizeof(float) * 2 * NB * 16 * (2 * GR_XLD + GR_HLD) + sizeof(int) * (NB * 16 + 4);
+}
+size_t fwd_gr_ring_bytes(const LstmArgs& a) {
+    return (size_t)16 * a.ND * HX_SLOTS * a.NS * a.H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6);
+}
+template <int NB, int KS>
+int launch_fwd_gr(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
+                  const float* w_hh, const int32_t* lens, float* y, float* hf, void* hx, float* gates, float* cs,
+                  SyncWords* sync, int* status) {
+    auto k = lstm_fwd_gr_kernel<NB, KS>;
+    LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LAS_HIP(hipMemsetAsync(hx, 0, fwd_gr_ring_bytes(a), st));          // tags of earlier launches must not match
+    hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT + 64), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
+                       (u32x4*)hx, gates, cs, sync, status);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
 template <int PREC, int NB, int KS>
 int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, const float* dy, const float* gates,
                const float* cs, const float* w_hh, const int32_t* lens, void* dgx, float* dgf, SyncWords* sync,
@@ -994,7 +1635,7 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
 
 
 // Which backward kernel a shape gets, its LDS request and the size of its exchange workspace (`dgx`).
-struct BwdPlan { bool ks, wdirect; int NB, NC, K4p; size_t lds, ws; };
+struct BwdPlan { bool ks, wdirect, gr; int NB, NC, K4p; size_t lds, ws; };
 int bwd_plan(int prec, int T, int B, int H, int ND, const LstmArgs& a, BwdPlan& p) {
     p.NB = las_pick_nb(a.Bs);
     if (p.NB == 0 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
@@ -1006,7 +1647,15 @@ int bwd_plan(int prec, int T, int B, int H, int ND, const LstmArgs& a, BwdPlan& 
         if (bwd_ks_lds(prec, H, p.NB, false) <= LDS_CAP && (prec != LAS_PREC_BF16 || mt <= 16)) p.ks = true;
         else if (prec == LAS_PREC_BF16 && mt <= 16 && bwd_ks_lds(prec, H, p.NB, true) <= LDS_CAP) p.ks = p.wdirect = true;
     }
-    if (p.ks) {
+    // tagged-granule hand-off (lstm_bwd_gr_kernel): bf16, <= 8 consumers per wave, <= 1 024 granules per inbox and step
+    p.gr = p.ks && prec == LAS_PREC_BF16 && (a.G + 3) / 4 <= 8 && H % 4 == 0 && (long)a.G * a.Bs * 4 <= 1024 &&
+           (long)T * B * ND * 4 * H * 4 < (1l << 31) && bwd_gr_lds(H, p.NB) <= LDS_CAP && !getenv("LAS_LSTM_NO_GR");
+    if (p.gr) {
+        p.wdirect = false;
+        p.lds = bwd_gr_lds(H, p.NB);
+        p.ws = bwd_gr_ring_bytes(a);
+        p.NC = 1; p.K4p = 4 * H;
+    } else if (p.ks) {
         p.lds = bwd_ks_lds(prec, H, p.NB, p.wdirect);
         p.ws = bwd_ks_ring_bytes(prec, H, ND, a.NS, p.NB);
         p.NC = 1; p.K4p = 4 * H;
@@ -1033,6 +1682,16 @@ extern "C" void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int
 
 extern "C" size_t las_lstm_sync_bytes(void) { return sizeof(SyncWords); }
 
+extern "C" size_t las_lstm_hx_bytes(int prec, int T, int B, int H, int ND) {
+    LstmArgs a;
+    if (check_common(T, B, H, ND, 1)) return 0;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    const size_t esz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4;
+    const size_t plain = (size_t)ND * HX_SLOTS * B * ((H + vec - 1) / vec * vec) * esz;     // [ND][4][B][Hx] ring of lstm_fwd_kernel
+    const size_t gr = fwd_gr_ring_bytes(a);                                                 // granule ring of lstm_fwd_gr_kernel
+    return las_align(plain > gr ? plain : gr);
+}
+
 extern "C" size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
     BwdPlan p;
@@ -1046,7 +1705,25 @@ extern "C" int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND) {
     BwdPlan p;
     if (check_common(T, B, H, ND, 1)) return 0;
     fill_args(a, T, B, H, ND, 16, 1, 0);
-    return bwd_plan(prec, T, B, H, ND, a, p) == LAS_OK && p.ks ? 1 : 0;
+    if (bwd_plan(prec, T, B, H, ND, a, p) != LAS_OK) return 0;
+    return p.gr ? 2 : p.ks ? 1 : 0;
+}
+
+// 1: lstm_fwd_gr_kernel (tagged-granule hand-off), 0: lstm_fwd_kernel.  Same rule as in las_lstm_rec_fwd below.
+static bool fwd_uses_gr(int prec, int T, int B, int H, int ND, const LstmArgs& a, int U, int NB, int KS) {
+    return prec == LAS_PREC_BF16 && KS > 0 && KS <= 16 && U == 16 && H % 4 == 0 && (long)T * B * ND * 4 * H * 4 < (1l << 31) &&
+           (long)H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6) <= 1024 && !getenv("LAS_LSTM_NO_GR");
+}
+extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
+    LstmArgs a;
+    if (check_common(T, B, H, ND, 1) || ND * ((H + 15) / 16) > 256) return 0;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    const int NB = las_pick_nb(a.Bs), ksteps = (H + 31) / 32;
+    int KS = 0;
+    if (prec == LAS_PREC_BF16 && NB >= 1 && NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT"))
+        KS = ksteps <= 8 ? 8 : ksteps <= 10 ? 10 : (ksteps <= 16 && NB == 1) ? 16 : 0;
+    const bool u8 = !a.xl && ND * ((H + 7) / 8) <= 256 && H == 512;
+    return fwd_uses_gr(prec, T, B, H, ND, a, u8 ? 8 : 16, NB, KS) ? 1 : 0;
 }
 
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
@@ -1085,6 +1762,15 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
+    if (fwd_uses_gr(prec, T, B, H, ND, a, U, NB, KS)) {
+        // tagged-granule hand-off (lstm_fwd_gr_kernel): no flag, no drain, one barrier per step
+        lds = fwd_gr_lds(H, NB);
+        if (lds < MIN_LDS) lds = MIN_LDS;
+        if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
+        if (KS == 10) { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
+        if (KS == 16) { return launch_fwd_gr<1, 16>(LAS_FWD_ARGS); }
+        // (KS = 32, H > 512: 128 registers of weight fragments per lane leave no room for a fifth wave on the CU)
+    }
     if (prec == LAS_PREC_BF16) {
         if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
         if (KS == 10) { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
@@ -1115,6 +1801,22 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     const size_t lds = p.lds;
     hipStream_t st = (hipStream_t)stream;
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
+    if (p.gr) {
+        LAS_HIP(hipMemsetAsync(dgx, 0, p.ws, st));                        // tags of earlier launches must not match
+#define LAS_GR_GO(N_, M_)                                                                                              \
+    {                                                                                                                 \
+        auto k = lstm_bwd_gr_kernel<N_, M_>;                                                                          \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT + 64), lds, st, a, dy, gates, cs, w_hh, lens, (u32x4*)dgx, dgf, \
+                           (SyncWords*)sync, status);                                                                 \
+        LAS_LAUNCH_OK();                                                                                              \
+        return LAS_OK;                                                                                                \
+    }
+        const int mt = (a.G + 3) / 4;
+        if (NB == 1) { if (mt <= 5) LAS_GR_GO(1, 5) else LAS_GR_GO(1, 8) }
+        else { if (mt <= 5) LAS_GR_GO(2, 5) else LAS_GR_GO(2, 8) }
+#undef LAS_GR_GO
+    }
     if (p.ks) {
 #define LAS_KS_GO(P_, N_, M_)                                                                                          \
     {                                                                                                                 \

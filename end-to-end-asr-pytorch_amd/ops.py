@@ -448,11 +448,12 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
     esz, vec = (2, 8) if _prec == 0 else (4, 4)
     Hx = (H + vec - 1) // vec * vec
-    hx = (torch.empty if Hx == H else torch.zeros)(ND * T * B * Hx * esz, dtype=torch.uint8, device=dev)
+    hx = (torch.empty if Hx == H else torch.zeros)(L_.las_lstm_hx_bytes(I(_prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
-    with _Timed('lstm_fwd_kernel', 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
+    kname = 'lstm_fwd_gr_kernel' if L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND)) else 'lstm_fwd_kernel'
+    with _Timed(kname, 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
                                   I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
                                   ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
@@ -473,7 +474,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
     ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
-    with _Timed('lstm_bwd_ks_kernel' if ksplit else 'lstm_bwd_kernel', 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
+    with _Timed(('lstm_bwd_kernel', 'lstm_bwd_ks_kernel', 'lstm_bwd_gr_kernel')[ksplit], 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
                                   I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
               'las_lstm_rec_bwd')

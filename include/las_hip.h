@@ -70,9 +70,9 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  *   xproj [T][B][ND*4H] (no bias), b_ih/b_hh [ND*4H], w_hh [ND][4H][H], lens [B] (desc. order not required)
  *   y     [T_out][B][F_out] layer output in next-layer layout (see las_lstm_out_shape); zero at t>=len
  *   hf    [T][B][ND*H] hidden history (fp32); may alias y when sr==1
- *   hx    exchange workspace in the MFMA operand type (bf16: 2 B/elem, Hx = H rounded up to 8; f32: 4 B/elem, Hx = H
- *         rounded up to 4): a ring [ND][4][B][Hx] of the last four steps' h (any size >= that, e.g. [ND][T][B][Hx]);
- *         when Hx != H the caller zero-fills it once
+ *   hx    exchange workspace of las_lstm_hx_bytes() bytes: a ring of the last four steps' h, either [ND][4][B][Hx] in the
+ *         MFMA operand type (bf16: Hx = H rounded up to 8; f32: rounded up to 4) or, in bf16 mode, tagged 16-byte
+ *         granules {6 batch rows of one unit, step tag} (zeroed by the call); when Hx != H the caller zero-fills it once
  *   gates [T][B][ND*4H] post-activation gates, cs [T][B][ND*H] cell states (saved for bwd)
  *   sync  las_lstm_sync_bytes() bytes of scratch; status: int32, caller-zeroed, set to LAS_E_TIMEOUT if
  *         the in-kernel hand-off spin gave up (all workgroups then exit; outputs are garbage).
@@ -81,8 +81,10 @@ int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out,
  * Limits: H % 2 == 0, B <= 2048 (the batch is cut into independent slices of <= 128 rows, normally ~12), ND*ceil(H/16) <= 256 (one workgroup per CU, all co-resident). */
 void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, int* F_out);
 size_t las_lstm_sync_bytes(void);
+size_t las_lstm_hx_bytes(int prec, int T, int B, int H, int ND);        /* size of the `hx` exchange workspace of rec_fwd */
 size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size of the `dgx` exchange workspace of rec_bwd */
-int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* 1: rec_bwd runs lstm_bwd_ks_kernel (reduce-scatter of partial dh), 0: lstm_bwd_kernel */
+int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* which kernel rec_bwd runs: 2 lstm_bwd_gr_kernel (reduce-scatter of partial dh in tagged granules), 1 lstm_bwd_ks_kernel (the same behind a flag), 0 lstm_bwd_kernel (all-gather of dgates) */
+int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND);       /* which kernel rec_fwd runs: 1 lstm_fwd_gr_kernel (tagged granules), 0 lstm_fwd_kernel */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
                      void* hx, float* gates, float* cs, void* sync, int* status, void* stream);

@@ -28,7 +28,7 @@ for (B, H, ND) in [(24, 320, 2), (12, 320, 2), (12, 320, 1), (24, 160, 2), (12, 
         y = ops.lstm_layer(x, lens, w_ih, w_hh, b_ih, b_hh, SR, True, status)
         y.backward(torch.ones_like(y))
     ops.join_side_stream(); torch.cuda.synchronize()
-    fw = [e0.elapsed_time(e1) for n, e0, e1, *_ in rec if n.startswith('lstm_rec_fwd')]
-    bw = [e0.elapsed_time(e1) for n, e0, e1, *_ in rec if n.startswith('lstm_rec_bwd')]
+    fw = [e0.elapsed_time(e1) for n, e0, e1, *_ in rec if n.startswith('lstm_fwd')]
+    bw = [e0.elapsed_time(e1) for n, e0, e1, *_ in rec if n.startswith('lstm_bwd')]
     ops.disable_kernel_timing()
     print(f'B={B:3d} H={H:4d} ND={ND} WGs/dir={H // 16:3d} slices={(B + 11) // 12}: fwd {min(fw) * 1e3 / T:.2f} us/step  bwd {min(bw) * 1e3 / T:.2f} us/step  status={status.item()}', flush=True)

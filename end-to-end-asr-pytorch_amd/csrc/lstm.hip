@@ -517,7 +517,7 @@ __device__ __forceinline__ u32x4 gr_poll(__amdgpu_buffer_rsrc_t rs, int off) {
 #ifdef LAS_PK_STAMPS            // diagnostic build only (make stamps): cycle sums per phase of a step, printed by workgroup 0
 #define GR_ST_DECL unsigned gst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gst_last = (unsigned)__builtin_amdgcn_s_memtime()
 #define GR_ST(i) do { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); gst[i] += now_ - gst_last; gst_last = now_; } while (0)
-#define GR_ST_PRINT(T) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) printf("gr stamps wave %d T=%d: sweep %u barrier %u mfma %u cell %u passes %u\n", (int)(threadIdx.x >> 6), T, gst[0] / T, gst[1] / T, gst[2] / T, gst[3] / T, gst[4]); } while (0)
+#define GR_ST_PRINT(T) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) printf("gr stamps wave %d T=%d: sweep %u barrier %u mfma/cell %u cell/mfma+store %u passes %u barrierB %u\n", (int)(threadIdx.x >> 6), T, gst[0] / T, gst[1] / T, gst[2] / T, gst[3] / T, gst[4], gst[5] / T); } while (0)
 #else
 #define GR_ST_DECL
 #define GR_ST(i)
@@ -770,6 +770,7 @@ GR_ST(1);
                 for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
                     for (int bt = 0; bt < NB; ++bt)
+                        // (predicating the read on `batch row < Bl` -- 6 of 16 rows in use -- made this phase SLOWER: 580 -> 800 cycles)
                         hv_[ks][bt] = *(const bf16x8*)(buf + (bt * 16 + fr) * ld + min((k0 + ks) * 32, Kp - 32) + fq * 8);
 #pragma unroll
                 for (int ks = 0; ks < CH; ++ks)
@@ -1266,7 +1267,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
     if (role.idle) return;
     const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
     const int b0 = bs * a.Bs, Bl = min(a.Bs, B - b0);
-    const int PS = (G + 3) & ~3, RLD = 16 * PS + 4;       // partial sums [row][column][producer], rows padded (banks)
+    constexpr int PS = MT * 4, RLD = 16 * PS + 4;         // partial sums [row][column][producer >= G: stays 0], rows padded (banks)
     bf16_t* Dl = (bf16_t*)smem;                           // [NB*16][LDK]        my dgates of this step (MFMA B operand)
     float* Red = (float*)(Dl + NB * 16 * LDK);            // [NB*16][RLD]
     float* Gi = Red + NB * 16 * RLD;                      // [2][NB*16][GR_XLD]  saved gates of the step   (I/O wave -> compute)
@@ -1349,21 +1350,24 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
         In x0, x1, x2;                                   // three sets: a value is used three phases after its request
         xload(0, x0); xload(1, x1); xload(2, x2);
         xstore(0, x0); xload(3, x0);
-        __syncthreads();                                 // A(0)
-        // phase s: B(s); hand over step s+1's inputs, request step s+4's, store step s's d gates; A(s+1)
+        xstore(1, x1); xload(4, x1);
+        __syncthreads();                                 // I: inputs of steps 0 and 1 in place
+        // step s: A(s); B(s); store step s's d gates, hand over step s+2's inputs (their buffer was last read before A(s),
+        // the compute waves want it after B(s+1): nothing of this wave's work sits between two barriers of one step),
+        // request step s+5's
         for (int s = 0;; s += 3) {
             __syncthreads();
-            xstore(s + 1, x1); xload(s + 4, x1); sflush(s, true);
+            __syncthreads();
+            sflush(s, true); xstore(s + 2, x2); xload(s + 5, x2);
             if (s + 1 >= a.T) break;
             __syncthreads();
             __syncthreads();
-            xstore(s + 2, x2); xload(s + 5, x2); sflush(s + 1, true);
+            sflush(s + 1, true); xstore(s + 3, x0); xload(s + 6, x0);
             if (s + 2 >= a.T) break;
             __syncthreads();
             __syncthreads();
-            xstore(s + 3, x0); xload(s + 6, x0); sflush(s + 2, true);
+            sflush(s + 2, true); xstore(s + 4, x1); xload(s + 7, x1);
             if (s + 3 >= a.T) break;
-            __syncthreads();
         }
         return;
     }
@@ -1410,8 +1414,34 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
         g_dst[u] = ok ? row * RLD + cg * 4 * PS + p : -1;
     }
 
-    for (int s = 0; s < a.T; ++s) {
+    // The part of the cell backward that does not depend on dh_{rec} is taken BEFORE the sweep, from inputs the I/O wave
+    // delivered a barrier earlier: dc = dh * ka + carry, d gates = dc * {k0, k1, k2}, dh * k3, carry' = dc * kf.
+    struct Pre { float dy, ka, k0, k1, k2, k3, kf; bool mq; };
+    Pre pre[NB];
+    auto precompute = [&](int s) {
         const int t = d == 0 ? a.T - 1 - s : s;
+        const float* gi_ = Gi + (s & 1) * NB * 16 * GR_XLD;
+        const float* ci_ = Ci + (s & 1) * NB * 16 * BG_CLD;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const int row = bt * 16 + fr;
+            const f32x4 g4 = *(const f32x4*)(gi_ + row * GR_XLD + ul * 4);
+            const f32x4 c4 = *(const f32x4*)(ci_ + row * BG_CLD + ul * 4);
+            const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3], tc = ftanh(c4[0]);
+            pre[bt].mq = evu && row < Bl && t < lensl[row];
+            pre[bt].dy = c4[2];
+            pre[bt].ka = og * (1.f - tc * tc);
+            pre[bt].k0 = gg * ig * (1.f - ig);
+            pre[bt].k1 = c4[1] * fg * (1.f - fg);
+            pre[bt].k2 = ig * (1.f - gg * gg);
+            pre[bt].k3 = tc * og * (1.f - og);
+            pre[bt].kf = fg;
+        }
+    };
+    __syncthreads();                                     // I: inputs of steps 0 and 1 in place
+    precompute(0);
+    GR_ST_DECL;
+    for (int s = 0; s < a.T; ++s) {
         if (s > 0) {
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ringg + ((s - 1) & (KS_SLOTS - 1)) * slot_stride), 0,
                                                                           G * G * RW * 16, 0x00020000);
@@ -1426,6 +1456,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                     got[u][0] = got[u][1] = 0u;
                     v[u] = gr_poll(rs, off[u]);
                 }
+                precompute(s);                           // (its inputs were delivered before B(s-1)): under the first poll's round trip
                 unsigned spins = 0;
                 while (true) {
                     bool need = false;
@@ -1437,6 +1468,9 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                         got[u][1] = hit ? v[u][1] : got[u][1];
                         need = need || off[u] != OOB;
                     }
+#ifdef LAS_PK_STAMPS
+                    ++gst[4];
+#endif
                     if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
 #pragma unroll
                     for (int u = 0; u < SW; ++u) v[u] = gr_poll(rs, off[u]);
@@ -1461,10 +1495,10 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                            : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
             if (!ok_) return;
         }
+        GR_ST(0);
         __syncthreads();                                 // A(s): partial sums complete, inputs of step s in Gi / Ci
-        // ---- pointwise BPTT of my elements -> my dgates of this step
-        const float* gi_ = Gi + (s & 1) * NB * 16 * GR_XLD;
-        const float* ci_ = Ci + (s & 1) * NB * 16 * BG_CLD;
+        GR_ST(1);
+        // ---- the rest of the pointwise BPTT of my elements -> my dgates of this step
         float* do_ = Do + (s & 1) * NB * 16 * GR_XLD;
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
@@ -1473,25 +1507,26 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
             if (s > 0) {
                 f32x4 acc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const float* rp = Red + row * RLD + ul * PS;
-                for (int p = 0; p < PS; p += 4) acc4 += *(const f32x4*)(rp + p);
+                f32x4 part[MT];                              // every read is issued before the first add
+#pragma unroll
+                for (int p = 0; p < MT; ++p) part[p] = *(const f32x4*)(rp + 4 * p);
+#pragma unroll
+                for (int p = 0; p < MT; ++p) acc4 += part[p];
                 dh_rec = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             }
-            const f32x4 g4 = *(const f32x4*)(gi_ + row * GR_XLD + ul * 4);
-            const f32x4 c4 = *(const f32x4*)(ci_ + row * BG_CLD + ul * 4);
-            const bool mq = evu && row < Bl && t < lensl[row];
-            const float ig = g4[0], fg = g4[1], gg = g4[2], og = g4[3], ct = c4[0], cp = c4[1];
-            const float dh = c4[2] + dh_rec;
-            const float tc = ftanh(ct);
-            const float dc = dh * og * (1.f - tc * tc) + dc_carry[bt];
-            const f32x4 dg = {mq ? dc * gg * ig * (1.f - ig) : 0.f, mq ? dc * cp * fg * (1.f - fg) : 0.f,
-                              mq ? dc * ig * (1.f - gg * gg) : 0.f, mq ? dh * tc * og * (1.f - og) : 0.f};
-            dc_carry[bt] = mq ? dc * fg : 0.f;
+            const bool mq = pre[bt].mq;
+            const float dh = pre[bt].dy + dh_rec;
+            const float dc = dh * pre[bt].ka + dc_carry[bt];
+            const f32x4 dg = {mq ? dc * pre[bt].k0 : 0.f, mq ? dc * pre[bt].k1 : 0.f, mq ? dc * pre[bt].k2 : 0.f, mq ? dh * pre[bt].k3 : 0.f};
+            dc_carry[bt] = mq ? dc * pre[bt].kf : 0.f;
             *(f32x4*)(do_ + row * GR_XLD + ul * 4) = dg;
             const unsigned lo = pack_bf16x2(dg[0], dg[1]), hi = pack_bf16x2(dg[2], dg[3]);
             bf16_t* dl = Dl + row * LDK + ul;
             dl[0] = (bf16_t)(lo & 0xffffu); dl[16] = (bf16_t)(lo >> 16); dl[32] = (bf16_t)(hi & 0xffffu); dl[48] = (bf16_t)(hi >> 16);
         }
+        GR_ST(2);
         __syncthreads();                                 // B(s): dgates tile complete, d gates of step s in Do
+        GR_ST(5);
         if (s + 1 < a.T) {
             // partial dh_{t-1}[:, 16 c .. 16 c + 15] for every consumer c; wave w takes c = w, w + 4, ...
             __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void*)(ringg + (s & (KS_SLOTS - 1)) * slot_stride), 0,
@@ -1501,27 +1536,36 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) dv[bt][ks] = *(const bf16x8*)(Dl + (bt * 16 + fr) * LDK + ks * 32 + fq * 8);
+            f32x4 acc[MT][NB];                           // all products first (independent accumulators), then the stores
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int c = wave + 4 * i;
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
-                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][0], dv[bt][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][1], dv[bt][1], acc, 0, 0, 0);
-                    // lane: batch row bt * 16 + fr, output columns 16 c + 4 fq + {0..3}
-                    const int row = bt * 16 + fr;
-                    const u32x4 gr = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), (unsigned)s + 1u, 0u};
-                    const int woff = (c < G && row < Bl) ? ((c * G + g) * RW + row * 4 + fq) * 16 : OOB;
-                    if (local) __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, 16);
+                    acc[i][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][0], dv[bt][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    acc[i][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[i][1], dv[bt][1], acc[i][bt], 0, 0, 0);
                 }
-            }
+            // lane: batch row bt * 16 + fr, output columns 16 c + 4 fq + {0..3}
+            auto put = [&](auto auxc) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int c = wave + 4 * i;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) {
+                        const int row = bt * 16 + fr;
+                        const u32x4 gr = {pack_bf16x2(acc[i][bt][0], acc[i][bt][1]), pack_bf16x2(acc[i][bt][2], acc[i][bt][3]), (unsigned)s + 1u, 0u};
+                        const int woff = (c < G && row < Bl) ? ((c * G + g) * RW + row * 4 + fq) * 16 : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(gr, ws, woff, 0, decltype(auxc)::value);
+                    }
+                }
+            };
+            if (local) put(std::integral_constant<int, 0>{}); else put(std::integral_constant<int, 16>{});
         }
+        GR_ST(3);
     }
+    GR_ST_PRINT(a.T);
 }
 size_t bwd_gr_lds(int H, int NB) {
-    const int G = (H + 15) / 16, PS = (G + 3) & ~3, RLD = 16 * PS + 4;
+    const int G = (H + 15) / 16, PS = (G + 3) / 4 <= 5 ? 20 : 32, RLD = 16 * PS + 4;
     return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4);
 }
 size_t bwd_gr_ring_bytes(const LstmArgs& a) { return (size_t)16 * KS_SLOTS * a.ND * a.NS * a.G * a.G * a.Bs * 4; }

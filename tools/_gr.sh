@@ -4,5 +4,3 @@ timeout -k 10 700 python -m pytest tests -q -x -m gpu > gpurun_out/gr_tests.log 
 tail -1 gpurun_out/gr_tests.log
 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/gr_bench_c3.json 2> gpurun_out/gr_bench_c3.err || { tail gpurun_out/gr_bench_c3.err; exit 3; }
 cut -c1-330 gpurun_out/gr_bench_c3.json
-timeout -k 10 300 python bench.py --workload c5 --steps 10 --warmup 5 --no-cpu-baseline > gpurun_out/gr_bench_c5.json 2> gpurun_out/gr_bench_c5.err || { tail gpurun_out/gr_bench_c5.err; exit 3; }
-cut -c1-330 gpurun_out/gr_bench_c5.json

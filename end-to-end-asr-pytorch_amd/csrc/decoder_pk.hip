@@ -5,9 +5,8 @@
 //
 // The loop is a chain of L dependent steps whose arithmetic is a few microseconds; per-step launches cost ~40 us.  Here
 // every workgroup lives for the whole loop (one per CU, all co-resident) and the step's four data hand-offs go through
-// the L2 / memory fabric with the persistent LSTM's protocol (MI355X_MICROARCH.md "Valid forms", row 1: sc1 stores,
-// every storing wave drains vmcnt(0), workgroup barrier, ONE lane adds to an agent-scope counter; consumers poll with
-// sc1 loads from one wave, barrier, then read the bytes with sc1 loads only).  Two roles:
+// the L2 / memory fabric as tagged 16-byte granules (pk_common.h: {payload, tag = step + 1} written with one sc1 store,
+// swept by the consumer with sc1 loads until every tag matches -- no flag, no drain, no atomic).  Two roles:
 //
 //   CELL workgroup (unit slice j of U hidden units, batch slice bs): keeps its 4U rows of [W_hh | W_ih(ctx part)] in LDS
 //     for all steps.  Per step: q_t tile = tanh(W_phi h_{t-1}) (published to the attention workgroups), gates = W_hh
@@ -36,14 +35,10 @@ namespace {
 constexpr int LOC_C = 10, LOC_K = 100, LOC_W = 2 * LOC_K + 1;     // reference asr.py:395-398
 constexpr int LWP = 208, NSEG = 4, SEGW = LWP / NSEG;              // taps padded with zeros, walked in 4 segments of 52
 constexpr float ATT_SCALE = 2.0f;                                 // reference asr.py:410
-constexpr int MAXB = 32, MAXNS = 4;
+constexpr int MAXB = 32;
 
 struct PkSync {                         // zeroed before every launch
     unsigned abort_[CLW];
-    unsigned cnt_q[MAXNS][CLW];         // per batch slice: q tiles published          (NQC per step)
-    unsigned cnt_h[MAXNS][CLW];         // per batch slice: h unit slices published    (NCT per step)
-    unsigned cnt_e[MAXB][CLW];          // per utterance: energy chunks published      (NCH per step)
-    unsigned cnt_c[MAXB][CLW];          // per utterance: context slices published     (NCH per step)
 };
 
 struct PkGeom {
@@ -52,6 +47,7 @@ struct PkGeom {
     int NCH, TC, ES;                    // attention role: parts per utterance, frames per part, context columns per part
     int Cp, Ep, Cx, Ex;                 // k extents padded to the MFMA k-step; exchange row strides (padded to a vector)
     int MT, NTW;                        // attention role: 16-frame tiles of a T'-chunk, 16-wide a-tiles per wave
+    int HG, CG, QG, TCG;                // granules: h per utterance, ctx per part, q per utterance, energies per part
     size_t lds;
 };
 
@@ -63,8 +59,7 @@ struct PkArgs {
     const float* w_ih; const float* w_hh; const float* b_hh; const float* w_phi;
     const float* conv_w; const float* w_lp; const float* w_e; const float* b_e;
     float* q; float* att; float* xin; float* hs; float* cs; float* gates; float* f; float* s;
-    void* hx; void* cx;                 // exchange rings [2][B][Cx], [2][B][Ex] in the compute type
-    float* ebuf;                        // [2][B][Tp]
+    u32x4 *hxg, *cxg, *qxg, *exg;       // granule rings [2][B][HG], [2][B][NCH*CG], [2][B][QG], [2][B][NCH*TCG]
     PkSync* sync; int* status;
     unsigned long long* dbg;            // [grid][12] cycle sums per phase (stamps build only)
 };
@@ -86,7 +81,6 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
     T* Xl = Wl + 4 * U * ld;
     T* Wq = Xl + NB * 16 * ld;
     float* Gl = (float*)(Wq + 16 * ldq);
-    int* flag = (int*)(Gl + PNW * NB * 16 * 17);
     const bool has_q = j < g.NQC;
 
     for (int i = threadIdx.x; i < 4 * U * ld; i += PNT) {
@@ -115,12 +109,40 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     const int tile = wave % NTILE, kp = wave / NTILE;
     unsigned* abort_word = a.sync->abort_;
-    unsigned nwait = 0;
-    T* hx = (T*)a.hx;
-    T* cx = (T*)a.cx;
+    constexpr int V12 = GrT<T>::V12, V8 = GrT<T>::V8;
+    // my shares of the two sweeps (granule i of wave w, slot u of lane l: w * Q + 64 u + l): ring offsets, LDS destinations
+    // and the number of payload words inside the row (the last part / unit group may reach beyond E / C) are fixed.
+    constexpr int SWM = 4;
+    const int nctx = Bl * g.NCH * g.CG, Qc = (nctx + PNW - 1) / PNW, swc = (Qc + 63) / 64;
+    const int nh = Bl * g.HG, Qh = (nh + PNW - 1) / PNW, swh = (Qh + 63) / 64;
+    int c_off[SWM], c_dst[SWM], c_nw[SWM], h_off[SWM], h_dst[SWM], h_nw[SWM];
+#pragma unroll
+    for (int u = 0; u < SWM; ++u) {
+        const int idx = lane + 64 * u;
+        {
+            const int i = wave * Qc + idx;
+            const bool ok = idx < Qc && i < nctx;
+            const int r = ok ? i / (g.NCH * g.CG) : 0, rest = ok ? i - r * (g.NCH * g.CG) : 0, cc = rest / g.CG, k = rest - cc * g.CG;
+            const int col = cc * g.ES + k * V12;
+            c_off[u] = ok ? ((b0 + r) * g.NCH * g.CG + rest) * 16 : GR_OOB;
+            c_dst[u] = r * ld + Cp + col;
+            c_nw[u] = ok ? max(0, min(3, (min(E, (cc + 1) * g.ES) - col + V12 / 3 - 1) / (V12 / 3))) : 0;
+        }
+        {
+            const int i = wave * Qh + idx;
+            const bool ok = idx < Qh && i < nh;
+            const int r = ok ? i / g.HG : 0, gq = ok ? i - r * g.HG : 0;
+            h_off[u] = ok ? ((b0 + r) * g.HG + gq) * 16 : GR_OOB;
+            h_dst[u] = r * ld + gq * V8;
+            h_nw[u] = ok ? max(0, min(2, (C - gq * V8 + V8 / 2 - 1) / (V8 / 2))) : 0;
+        }
+    }
+    const int slot_c = B * g.NCH * g.CG, slot_h = B * g.HG, slot_q = B * g.QG;
+    auto fail = [&]() { *a.status = LAS_E_TIMEOUT; };
     PK_STAMP_DECL;
 
     for (int t = 0; t < a.L; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
         // ---- (1) q_t tile = tanh(W_phi[16 j .. ] h_{t-1}) for my batch slice; t = 0: h = 0
         if (has_q) {
             f32x4 qa[NB];
@@ -138,9 +160,14 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < PNW; ++w) v += Gl[(w * NB * 16 + row) * 17 + col];
-                if (row < Bl && j * 16 + col < A) st_sc1(a.q + ((long)t * B + b0 + row) * A + j * 16 + col, fast_tanh(v));
+                const bool okq = row < Bl && j * 16 + col < A;
+                const float qv_ = okq ? fast_tanh(v) : 0.f;
+                if (okq) __builtin_nontemporal_store(qv_, a.q + ((long)t * B + b0 + row) * A + j * 16 + col);      // saved for the backward pass
+                unsigned w[3];
+                pk_gr_gather8<float>(qv_, w);                    // q travels in f32: 2 values per granule
+                __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.qxg + (t & 1) * slot_q), 0, slot_q * 16, 0x00020000);
+                pk_gr_store(rq, (okq && !(col & 1)) ? ((b0 + row) * g.QG + (j * 16 + col) / 2) * 16 : GR_OOB, w[0], w[1], 0u, tag);
             }
-            pk_signal(&a.sync->cnt_q[bs][0]);
         }
         PK_STAMP(0);
         // ---- (2) recurrent half of the gates; the embedding half + b_ih comes precomputed
@@ -154,12 +181,27 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
             for (int ks = kp; ks < Cp / KSTEP; ks += KP) mma_rows<PREC, NB>(acc, Xl + ks * KSTEP, ld, Wl + tile * 16 * ld + ks * KSTEP, ld, 1);
         PK_STAMP(1);
         // ---- (3) context of this step from the attention workgroups of my batch rows
-        if (!pk_block_wait(&a.sync->cnt_c[b0][0], CLW, Bl, (unsigned)g.NCH * (t + 1), abort_word, flag + (nwait++ & 1))) {
-            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-            return;
+        {
+            __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cxg + (t & 1) * slot_c), 0, slot_c * 16, 0x00020000);
+            auto sweep = [&](auto swv) -> bool {
+                constexpr int SW = decltype(swv)::value;
+                int off[SW];
+                u32x4 got[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) off[u] = c_off[u];
+                if (!pk_gr_sweep<SW>(rc, off, tag, abort_word, got)) return false;
+#pragma unroll
+                for (int u = 0; u < SW; ++u)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (e < c_nw[u]) ((unsigned*)(Xl + c_dst[u]))[e] = got[u][e];
+                return true;
+            };
+            const bool ok = swc <= 1 ? sweep(std::integral_constant<int, 1>{}) : swc == 2 ? sweep(std::integral_constant<int, 2>{})
+                          : swc == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            if (!ok) { fail(); return; }
         }
         PK_STAMP(2);
-        pk_pull<T, VEC, 4>(cx + ((long)(t & 1) * B + b0) * g.Ex, Bl, g.Ex, g.Ex, Xl + Cp, ld);
         __syncthreads();
         for (int ks = kp; ks < Ep / KSTEP; ks += KP) mma_rows<PREC, NB>(acc, Xl + Cp + ks * KSTEP, ld, Wl + tile * 16 * ld + Cp + ks * KSTEP, ld, 1);
 #pragma unroll
@@ -181,9 +223,12 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
         const float cn = fg * c_state + ig * gg;
         const float hn = ev ? og * fast_tanh(cn) : 0.f;
         c_state = cn;
-        const float hnext = las_dpp<0x101, 0xf>(0.f, hn);               // unit en + 1 (U is even, so pairs never straddle rows)
-        if (ev && !(en & 1)) st_pair_sc1(hx + ((long)(t & 1) * B + b0 + er) * g.Cx + ej, hn, hnext);
-        pk_signal(&a.sync->cnt_h[bs][0]);
+        {
+            unsigned w[3];
+            pk_gr_gather8<T>(hn, w);                             // units en .. en + V8 - 1 of my row (U is a multiple of V8)
+            __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.hxg + (t & 1) * slot_h), 0, slot_h * 16, 0x00020000);
+            pk_gr_store(rh, (ev && en % V8 == 0) ? ((b0 + er) * g.HG + ej / V8) * 16 : GR_OOB, w[0], w[1], 0u, tag);
+        }
         PK_STAMP(4);
         if (ev) {
             const long ro = (long)t * B + b0 + er;
@@ -198,12 +243,25 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
         PK_STAMP(5);
         // ---- (5) all-gather h_t of my batch slice for the next step
         if (t + 1 < a.L) {
-            if (!pk_block_wait(&a.sync->cnt_h[bs][0], 0, 1, (unsigned)g.NCT * (t + 1), abort_word, flag + (nwait++ & 1))) {
-                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-                return;
-            }
+            __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.hxg + (t & 1) * slot_h), 0, slot_h * 16, 0x00020000);
+            auto sweep = [&](auto swv) -> bool {
+                constexpr int SW = decltype(swv)::value;
+                int off[SW];
+                u32x4 got[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) off[u] = h_off[u];
+                if (!pk_gr_sweep<SW>(rh, off, tag, abort_word, got)) return false;
+#pragma unroll
+                for (int u = 0; u < SW; ++u)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (e < h_nw[u]) ((unsigned*)(Xl + h_dst[u]))[e] = got[u][e];
+                return true;
+            };
+            const bool ok = swh <= 1 ? sweep(std::integral_constant<int, 1>{}) : swh == 2 ? sweep(std::integral_constant<int, 2>{})
+                          : swh == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            if (!ok) { fail(); return; }
             PK_STAMP(6);
-            pk_pull<T, VEC, 2>(hx + ((long)(t & 1) * B + b0) * g.Cx, Bl, g.Cx, g.Cx, Xl, ld);
             __syncthreads();
             PK_STAMP(7);
         }
@@ -222,7 +280,6 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
     const PkGeom& g = a.g;
     const int id = blockIdx.x - g.NCELL, b = id / g.NCH, c = id - b * g.NCH;
-    const int bs = b / g.Bs;
     const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E;
     const int len = a.lens[b];
     const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0));
@@ -240,8 +297,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     float* e_l = q_l + A4;                                       // [Tp4]
     float* ep_l = e_l + Tp4;                                     // [8 waves][MT*16] partial energies
     float* red = ep_l + PNW * MT * 16;                           // [64]
-    int* flag = (int*)(red + 64);                                // [4]
-    T* Ft = (T*)(flag + 4);                                      // [MT*16][LDK] location features of my frames (frames x channels)
+    T* Ft = (T*)(red + 64 + 4);                                     // [MT*16][LDK] location features of my frames (frames x channels)
     T* Wt = Ft + MT * 16 * LDK;                                  // [NTW*8*16][LDK] W_lp rows (a x channels), zero padded
     // my copy of the attention is shifted so that frame r0 sits on a 16-byte boundary: att0[LOC_K + t'] = att[t']
     float* att0 = att_l + ((4 - ((r0 + LOC_K) & 3)) & 3);
@@ -280,8 +336,24 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? we_l[aa] : 0.f; }
     const float be = a.b_e[0];
     unsigned* abort_word = a.sync->abort_;
-    unsigned nwait = 0;
-    T* cx = (T*)a.cx;
+    constexpr int V12 = GrT<T>::V12;
+    // my shares of the two sweeps (q of my utterance: QG granules of 2 f32; its energies: NCH * TCG granules of 2 f32)
+    constexpr int SWA = 2;
+    const int ne = g.NCH * g.TCG;
+    int q_off[SWA], q_dst[SWA], e_off[SWA], e_dst[SWA];
+    bool e_two[SWA];
+#pragma unroll
+    for (int u = 0; u < SWA; ++u) {
+        const int i = threadIdx.x + u * PNT;
+        q_off[u] = i < g.QG ? (b * g.QG + i) * 16 : GR_OOB;
+        q_dst[u] = 2 * i;
+        const int cc = i / g.TCG, k = i - cc * g.TCG;
+        e_off[u] = i < ne ? (b * ne + i) * 16 : GR_OOB;
+        e_dst[u] = cc * TC + 2 * k;
+        e_two[u] = 2 * k + 1 < TC;
+    }
+    const int slot_c = B * g.NCH * g.CG, slot_q = B * g.QG, slot_e = B * ne;
+    auto fail = [&]() { *a.status = LAS_E_TIMEOUT; };
     // this thread's (first) conv work item and reduction element: fixed for the whole loop
     const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
               cv_qd = threadIdx.x - cv_sg * (LOC_C * TCq) - cv_cc * TCq;
@@ -340,14 +412,29 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             }
         PK_STAMP(1);
         // ---- (B) q_t from the cell workgroups of my batch slice
-        if (!pk_block_wait(&a.sync->cnt_q[bs][0], 0, 1, (unsigned)g.NQC * (t + 1), abort_word, flag + (nwait++ & 1))) {
-            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-            return;
+        const unsigned tag = (unsigned)t + 1u;
+        {
+            __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.qxg + (t & 1) * slot_q), 0, slot_q * 16, 0x00020000);
+            auto sweep = [&](auto swv) -> bool {
+                constexpr int SW = decltype(swv)::value;
+                int off[SW];
+                u32x4 got[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) off[u] = q_off[u];
+                if (!pk_gr_sweep<SW>(rq, off, tag, abort_word, got)) return false;
+#pragma unroll
+                for (int u = 0; u < SW; ++u)
+                    if (q_off[u] != GR_OOB) { q_l[q_dst[u]] = __uint_as_float(got[u][0]); q_l[q_dst[u] + 1] = __uint_as_float(got[u][1]); }
+                return true;
+            };
+            const bool ok = g.QG <= PNT ? sweep(std::integral_constant<int, 1>{}) : sweep(std::integral_constant<int, 2>{});
+            if (!ok) { fail(); return; }
         }
+        __syncthreads();
         PK_STAMP(2);
         float qv[NTW];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) qv[j] = ld_sc1(a.q + ((long)t * B + b) * A + min((wave + PNW * j) * 16 + fr, A - 1));
+        for (int j = 0; j < NTW; ++j) qv[j] = q_l[min((wave + PNW * j) * 16 + fr, A - 1)];
         // ---- (C) energies of my frames: e = w_e . tanh(psi + q + u) + b_e   (reference asr.py:453); s overwrites u
         float er_[MT][4];
 #pragma unroll
@@ -375,27 +462,45 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
                 for (int r = 0; r < 4; ++r) ep_l[wave * MT * 16 + mt * 16 + fq * 4 + r] = er_[mt][r];
         }
         __syncthreads();
-        if (threadIdx.x < TCr) {
+        if (threadIdx.x < MT * 16) {                             // (whole waves: the granule gather runs on DPP)
+            const bool act = (int)threadIdx.x < TCr;
             float v = be;
 #pragma unroll
             for (int w = 0; w < PNW; ++w) v += ep_l[w * MT * 16 + threadIdx.x];
-            st_sc1(a.ebuf + ((long)(t & 1) * B + b) * Tp + r0 + threadIdx.x, r0 + (int)threadIdx.x < len ? v : 0.f);
+            v = (act && r0 + (int)threadIdx.x < len) ? v : 0.f;
+            unsigned w2[3];
+            pk_gr_gather8<float>(v, w2);                         // energies travel in f32: 2 frames per granule
+            __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(a.exg + (t & 1) * slot_e), 0, slot_e * 16, 0x00020000);
+            // (every part publishes all its TCG granules, zeros beyond the utterance: the readers wait for each of them)
+            pk_gr_store(re, (!(threadIdx.x & 1) && (int)threadIdx.x / 2 < g.TCG) ? ((b * g.NCH + c) * g.TCG + (int)threadIdx.x / 2) * 16 : GR_OOB, w2[0], w2[1], 0u, tag);
         }
-        pk_signal(&a.sync->cnt_e[b][0]);
         PK_STAMP(3);
         PK_STAMP(4);
         // ---- (D) all energies of my utterance; masked softmax(2 e) (reference asr.py:454-455), redundantly per part
-        if (!pk_block_wait(&a.sync->cnt_e[b][0], 0, 1, (unsigned)g.NCH * (t + 1), abort_word, flag + (nwait++ & 1))) {
-            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-            return;
+        {
+            __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(a.exg + (t & 1) * slot_e), 0, slot_e * 16, 0x00020000);
+            auto sweep = [&](auto swv) -> bool {
+                constexpr int SW = decltype(swv)::value;
+                int off[SW];
+                u32x4 got[SW];
+#pragma unroll
+                for (int u = 0; u < SW; ++u) off[u] = e_off[u];
+                if (!pk_gr_sweep<SW>(re, off, tag, abort_word, got)) return false;
+#pragma unroll
+                for (int u = 0; u < SW; ++u)
+                    if (e_off[u] != GR_OOB) {
+                        if (e_dst[u] < Tp4) e_l[e_dst[u]] = ATT_SCALE * __uint_as_float(got[u][0]);
+                        if (e_two[u] && e_dst[u] + 1 < Tp4) e_l[e_dst[u] + 1] = ATT_SCALE * __uint_as_float(got[u][1]);   // (odd TC: the last granule's second frame belongs to the next part)
+                    }
+                return true;
+            };
+            const bool ok = ne <= PNT ? sweep(std::integral_constant<int, 1>{}) : sweep(std::integral_constant<int, 2>{});
+            if (!ok) { fail(); return; }
         }
+        __syncthreads();
         PK_STAMP(5);
         float m = -INFINITY;
-        for (int i = threadIdx.x; i < len; i += PNT) {
-            const float v = ATT_SCALE * ld_sc1(a.ebuf + ((long)(t & 1) * B + b) * Tp + i);
-            e_l[i] = v;
-            m = fmaxf(m, v);
-        }
+        for (int i = threadIdx.x; i < len; i += PNT) m = fmaxf(m, e_l[i]);
         m = block_max(m, red);
         float sum = 0.f;
         for (int i = threadIdx.x; i < len; i += PNT) { const float v = expf(e_l[i] - m); e_l[i] = v; sum += v; }
@@ -419,15 +524,20 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         }
         __syncthreads();
         {
-            const int col = threadIdx.x;
+            // 12 consecutive columns in lanes 0..11 of every 16-lane row: a granule's 3 f32 / 6 bf16 come over DPP row shifts
+            const int kk = threadIdx.x >> 4, l = threadIdx.x & 15, col = 12 * kk + l;
+            const bool cv = l < 12 && col < ES;
             float v = 0.f;
-            if (col < ES) for (int tg = 0; tg < NTG; ++tg) v += part_l[tg * ES + col];
-            const float vnext = las_dpp<0x101, 0xf>(0.f, v);
-            if (col < ESr && !(col & 1)) st_pair_sc1(cx + ((long)(t & 1) * B + b) * g.Ex + e0 + col, v, col + 1 < ESr ? vnext : 0.f);
-            pk_signal(&a.sync->cnt_c[b][0]);
+            if (cv) for (int tg = 0; tg < NTG; ++tg) v += part_l[tg * ES + col];
+            v = (cv && col < ESr) ? v : 0.f;
+            unsigned w3[3];
+            pk_gr_gather12<T>(v, w3);
+            __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cxg + (t & 1) * slot_c), 0, slot_c * 16, 0x00020000);
+            const int gk = kk * (12 / V12) + l / V12;              // granule gk = columns [V12 gk, V12 gk + V12) of my slice
+            pk_gr_store(rc, (l < 12 && l % V12 == 0 && gk < g.CG) ? ((b * g.NCH + c) * g.CG + gk) * 16 : GR_OOB, w3[0], w3[1], w3[2], tag);
             PK_STAMP(7);
             // saved for the backward pass (after the hand-off): the context, and the attention map from part 0
-            if (col < ESr) a.xin[((long)t * B + b) * XI + C + e0 + col] = v;
+            if (cv && col < ESr) a.xin[((long)t * B + b) * XI + C + e0 + col] = v;
             if (c == 0)
                 for (int i = threadIdx.x; i < Tp; i += PNT) a.att[((long)(t + 1) * B + b) * Tp + i] = att0[LOC_K + i];
         }
@@ -511,6 +621,15 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
         g.ES = ((d->E + g.NCH - 1) / g.NCH + 3) / 4 * 4;
         if (g.ES / 4 > PNT || g.ES > PNT) continue;
         if (att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
+        // granule counts (12-byte payload: 3 f32 / 6 bf16; 8-byte payload: 2 f32 / 4 bf16) and the sweeps' limits
+        const int v12 = d->prec == LAS_PREC_BF16 ? 6 : 3, v8 = d->prec == LAS_PREC_BF16 ? 4 : 2;
+        if ((d->E & 1) || g.U % v8 != 0) continue;
+        g.HG = (d->C + v8 - 1) / v8;
+        g.CG = (g.ES + v12 - 1) / v12;
+        g.QG = (d->A + 1) / 2;
+        g.TCG = (g.TC + 1) / 2;
+        if (g.Bs * g.HG > 4 * PNT || g.Bs * g.NCH * g.CG > 4 * PNT || g.QG > 2 * PNT || g.NCH * g.TCG > 2 * PNT) continue;
+        if ((g.ES + 11) / 12 * 16 > PNT) continue;
         g.lds = cell_lds(d->prec, g, d->C, d->E);
         const size_t al = att_lds(d->prec, g, d->Tp, d->A);
         if (al > g.lds) g.lds = al;
@@ -521,16 +640,16 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
     return false;
 }
 
-struct WsLayout { size_t sync, hx, cx, ebuf, dbg, xe, total; };
+struct WsLayout { size_t sync, hxg, cxg, qxg, exg, dbg, xe, total; };
 WsLayout ws_layout(const las_dec_dims* d, const PkGeom& g) {
-    const size_t sz = d->prec == LAS_PREC_BF16 ? 2 : 4;
     WsLayout w;
     size_t o = 0;
     w.sync = o; o += las_align(sizeof(PkSync));
     w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 20);      // (read by tools/pk_stamps.py in the stamps build)
-    w.hx = o; o += las_align((size_t)2 * d->B * g.Cx * sz);
-    w.cx = o; o += las_align((size_t)2 * d->B * g.Ex * sz);
-    w.ebuf = o; o += las_align(sizeof(float) * 2 * d->B * d->Tp);
+    w.hxg = o; o += las_align((size_t)16 * 2 * d->B * g.HG);
+    w.cxg = o; o += las_align((size_t)16 * 2 * d->B * g.NCH * g.CG);
+    w.qxg = o; o += las_align((size_t)16 * 2 * d->B * g.QG);
+    w.exg = o; o += las_align((size_t)16 * 2 * d->B * g.NCH * g.TCG);
     w.xe = o; o += las_align(sizeof(float) * (size_t)d->L * d->B * 4 * d->C);
     w.total = o;
     return w;
@@ -552,7 +671,7 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     const WsLayout w = ws_layout(d, g);
     char* ws = (char*)st->pk_ws;
     const int B = d->B, C = d->C, E = d->E, XI = C + E, L = d->L;
-    // counters, exchange rings (their pad columns must read as zero) and the energy ring
+    // abort word and the granule rings (no tag of an earlier launch may match)
     LAS_HIP(hipMemsetAsync(ws, 0, w.xe, stream));
     // xe[t][b][:] = W_ih[:, 0:C] emb(tok[t][b]) + b_ih for every step: one MFMA GEMM instead of L skinny k-segments
     float* xe = (float*)(ws + w.xe);
@@ -565,7 +684,7 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     a.w_ih = p->w_ih[0]; a.w_hh = p->w_hh[0]; a.b_hh = p->b_hh[0]; a.w_phi = p->w_phi;
     a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e; a.b_e = p->b_e;
     a.q = st->q; a.att = st->att; a.xin = st->xin; a.hs = st->hs; a.cs = st->cs; a.gates = st->gates; a.f = st->f; a.s = st->s;
-    a.hx = ws + w.hx; a.cx = ws + w.cx; a.ebuf = (float*)(ws + w.ebuf);
+    a.hxg = (u32x4*)(ws + w.hxg); a.cxg = (u32x4*)(ws + w.cxg); a.qxg = (u32x4*)(ws + w.qxg); a.exg = (u32x4*)(ws + w.exg);
     a.sync = (PkSync*)(ws + w.sync); a.status = st->pk_status;
     a.dbg = (unsigned long long*)(ws + w.dbg);
     const int grid = g.NCELL + B * g.NCH;

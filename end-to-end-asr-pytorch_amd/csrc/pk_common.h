@@ -3,6 +3,7 @@
 // barrier, ONE lane adds to an agent-scope counter; consumers poll with sc1 loads from one wave, barrier, then read the
 // bytes with sc1 loads only), tile pulls, and the diagnostic cycle stamps.
 #pragma once
+#include <type_traits>
 #include "las_mma.h"
 
 namespace {
@@ -66,6 +67,86 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- tagged granules (MI355X_MICROARCH.md "R2": a naturally aligned 16-byte store is observed untorn by 16-byte sc1 loads
+// on gfx950; not an architectural guarantee) ------------------------------------------------------------------------
+// A hand-off without flag, drain or atomic: the payload travels as 16-byte granules {<= 12 bytes of data, tag = step + 1}
+// written by ONE lane with ONE sc1 store; the rings are zeroed before the launch, so a tag can only be matched by this
+// launch's store of that step.  The consumer sweeps its granules (one 16-byte sc1 load per granule and pass, consecutive
+// lanes <-> consecutive granules) until every tag matches: in steady state the first pass does, and a hop costs one L2
+// round trip instead of drain + barrier + atomic + poll + barrier + pull (the flag form was ~2 us per hop here).
+constexpr int GR_OOB = 0x7ffffff0;                                // an offset beyond every ring: returns zeros, no memory traffic
+__device__ __forceinline__ u32x4 pk_gr_poll(__amdgpu_buffer_rsrc_t rs, int off) {
+    asm volatile("" : "+v"(off));                                 // identical polls must neither be merged nor hoisted
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+}
+// Sweep SW granules per lane (byte offsets goff, GR_OOB = none) until each carries `tag`; uniform over the wave, branch-free.
+template <int SW>
+__device__ __forceinline__ bool pk_gr_sweep(__amdgpu_buffer_rsrc_t rs, const int (&goff)[SW], unsigned tag, unsigned* abort_word,
+                                            u32x4 (&got)[SW]) {
+    int off[SW];
+    u32x4 v[SW];
+#pragma unroll
+    for (int u = 0; u < SW; ++u) {
+        off[u] = goff[u];
+        got[u] = (u32x4){0u, 0u, 0u, 0u};
+        v[u] = pk_gr_poll(rs, off[u]);
+    }
+    unsigned spins = 0;
+    while (true) {
+        bool need = false;
+#pragma unroll
+        for (int u = 0; u < SW; ++u) {
+            const bool hit = off[u] != GR_OOB && v[u][3] == tag;
+            off[u] = hit ? GR_OOB : off[u];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) got[u][e] = hit ? v[u][e] : got[u][e];
+            need = need || off[u] != GR_OOB;
+        }
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) return true;
+#pragma unroll
+        for (int u = 0; u < SW; ++u) v[u] = pk_gr_poll(rs, off[u]);
+        if ((++spins & 255u) == 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || spins > PK_SPIN) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void pk_gr_store(__amdgpu_buffer_rsrc_t rs, int off, unsigned w0, unsigned w1, unsigned w2, unsigned tag) {
+    const u32x4 g = {w0, w1, w2, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 16);     // sc1: the consumers sit on other XCDs
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned pk_dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// Payload words of the granule that STARTS at this lane, from one value per lane in consecutive lanes of a 16-lane row
+// (row_shl: lanes beyond the row read 0).  12-byte payload: 3 f32 / 6 bf16 per granule; 8-byte payload: 2 f32 / 4 bf16.
+template <typename T> struct GrT;
+template <> struct GrT<float>  { static constexpr int V12 = 3, V8 = 2; };
+template <> struct GrT<bf16_t> { static constexpr int V12 = 6, V8 = 4; };
+template <typename T>
+__device__ __forceinline__ void pk_gr_gather12(float v, unsigned (&w)[3]) {
+    if constexpr (sizeof(T) == 4) {
+        w[0] = __float_as_uint(v); w[1] = pk_dpp_u<0x101>(w[0]); w[2] = pk_dpp_u<0x102>(w[0]);
+    } else {
+        w[0] = pack_bf16x2(v, __uint_as_float(pk_dpp_u<0x101>(__float_as_uint(v)))); w[1] = pk_dpp_u<0x102>(w[0]); w[2] = pk_dpp_u<0x104>(w[0]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void pk_gr_gather8(float v, unsigned (&w)[3]) {
+    if constexpr (sizeof(T) == 4) {
+        w[0] = __float_as_uint(v); w[1] = pk_dpp_u<0x101>(w[0]); w[2] = 0u;
+    } else {
+        w[0] = pack_bf16x2(v, __uint_as_float(pk_dpp_u<0x101>(__float_as_uint(v)))); w[1] = pk_dpp_u<0x102>(w[0]); w[2] = 0u;
+    }
+}
+// The first NW payload words of a matched granule into an LDS row of T (4-byte aligned destination).
+template <typename T, int NW>
+__device__ __forceinline__ void pk_gr_scatter(T* dst, const u32x4& g) {
+#pragma unroll
+    for (int e = 0; e < NW; ++e) ((unsigned*)dst)[e] = g[e];
+}
+
 // exchange store of the pair (a, b) at consecutive columns, sc1 (write-through): 4 bytes (bf16) / 8 bytes (f32)
 __device__ __forceinline__ void st_pair_sc1(bf16_t* p, float a, float b) {
     __hip_atomic_store((unsigned*)p, pack_bf16x2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

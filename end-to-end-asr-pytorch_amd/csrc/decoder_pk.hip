@@ -186,16 +186,13 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
             auto sweep = [&](auto swv) -> bool {
                 constexpr int SW = decltype(swv)::value;
                 int off[SW];
-                u32x4 got[SW];
 #pragma unroll
                 for (int u = 0; u < SW; ++u) off[u] = c_off[u];
-                if (!pk_gr_sweep<SW>(rc, off, tag, abort_word, got)) return false;
-#pragma unroll
-                for (int u = 0; u < SW; ++u)
+                return pk_gr_sweep<SW>(rc, off, tag, abort_word, [&](int u, const u32x4& gv) {
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
-                        if (e < c_nw[u]) ((unsigned*)(Xl + c_dst[u]))[e] = got[u][e];
-                return true;
+                        if (e < c_nw[u]) ((unsigned*)(Xl + c_dst[u]))[e] = gv[e];
+                });
             };
             const bool ok = swc <= 1 ? sweep(std::integral_constant<int, 1>{}) : swc == 2 ? sweep(std::integral_constant<int, 2>{})
                           : swc == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
@@ -247,16 +244,13 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
             auto sweep = [&](auto swv) -> bool {
                 constexpr int SW = decltype(swv)::value;
                 int off[SW];
-                u32x4 got[SW];
 #pragma unroll
                 for (int u = 0; u < SW; ++u) off[u] = h_off[u];
-                if (!pk_gr_sweep<SW>(rh, off, tag, abort_word, got)) return false;
-#pragma unroll
-                for (int u = 0; u < SW; ++u)
+                return pk_gr_sweep<SW>(rh, off, tag, abort_word, [&](int u, const u32x4& gv) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e)
-                        if (e < h_nw[u]) ((unsigned*)(Xl + h_dst[u]))[e] = got[u][e];
-                return true;
+                        if (e < h_nw[u]) ((unsigned*)(Xl + h_dst[u]))[e] = gv[e];
+                });
             };
             const bool ok = swh <= 1 ? sweep(std::integral_constant<int, 1>{}) : swh == 2 ? sweep(std::integral_constant<int, 2>{})
                           : swh == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
@@ -418,14 +412,11 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             auto sweep = [&](auto swv) -> bool {
                 constexpr int SW = decltype(swv)::value;
                 int off[SW];
-                u32x4 got[SW];
 #pragma unroll
                 for (int u = 0; u < SW; ++u) off[u] = q_off[u];
-                if (!pk_gr_sweep<SW>(rq, off, tag, abort_word, got)) return false;
-#pragma unroll
-                for (int u = 0; u < SW; ++u)
-                    if (q_off[u] != GR_OOB) { q_l[q_dst[u]] = __uint_as_float(got[u][0]); q_l[q_dst[u] + 1] = __uint_as_float(got[u][1]); }
-                return true;
+                return pk_gr_sweep<SW>(rq, off, tag, abort_word, [&](int u, const u32x4& gv) {
+                    q_l[q_dst[u]] = __uint_as_float(gv[0]); q_l[q_dst[u] + 1] = __uint_as_float(gv[1]);
+                });
             };
             const bool ok = g.QG <= PNT ? sweep(std::integral_constant<int, 1>{}) : sweep(std::integral_constant<int, 2>{});
             if (!ok) { fail(); return; }
@@ -482,17 +473,12 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             auto sweep = [&](auto swv) -> bool {
                 constexpr int SW = decltype(swv)::value;
                 int off[SW];
-                u32x4 got[SW];
 #pragma unroll
                 for (int u = 0; u < SW; ++u) off[u] = e_off[u];
-                if (!pk_gr_sweep<SW>(re, off, tag, abort_word, got)) return false;
-#pragma unroll
-                for (int u = 0; u < SW; ++u)
-                    if (e_off[u] != GR_OOB) {
-                        if (e_dst[u] < Tp4) e_l[e_dst[u]] = ATT_SCALE * __uint_as_float(got[u][0]);
-                        if (e_two[u] && e_dst[u] + 1 < Tp4) e_l[e_dst[u] + 1] = ATT_SCALE * __uint_as_float(got[u][1]);   // (odd TC: the last granule's second frame belongs to the next part)
-                    }
-                return true;
+                return pk_gr_sweep<SW>(re, off, tag, abort_word, [&](int u, const u32x4& gv) {
+                    if (e_dst[u] < Tp4) e_l[e_dst[u]] = ATT_SCALE * __uint_as_float(gv[0]);
+                    if (e_two[u] && e_dst[u] + 1 < Tp4) e_l[e_dst[u] + 1] = ATT_SCALE * __uint_as_float(gv[1]);   // (odd TC: the last granule's second frame belongs to the next part)
+                });
             };
             const bool ok = ne <= PNT ? sweep(std::integral_constant<int, 1>{}) : sweep(std::integral_constant<int, 2>{});
             if (!ok) { fail(); return; }

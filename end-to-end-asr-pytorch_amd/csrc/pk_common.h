@@ -80,15 +80,16 @@ __device__ __forceinline__ u32x4 pk_gr_poll(__amdgpu_buffer_rsrc_t rs, int off) 
     return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
 }
 // Sweep SW granules per lane (byte offsets goff, GR_OOB = none) until each carries `tag`; uniform over the wave, branch-free.
-template <int SW>
-__device__ __forceinline__ bool pk_gr_sweep(__amdgpu_buffer_rsrc_t rs, const int (&goff)[SW], unsigned tag, unsigned* abort_word,
-                                            u32x4 (&got)[SW]) {
+// Sweep SW granules per lane (byte offsets goff, GR_OOB = none) until each carries `tag`; uniform over the wave.  A matched
+// granule is handed to on_hit(u, granule) at once (an exec-masked LDS write at the call sites): keeping the matched
+// payloads in registers until the end of the sweep cost 4 SW registers at the point of the roles' highest pressure.
+template <int SW, typename F>
+__device__ __forceinline__ bool pk_gr_sweep(__amdgpu_buffer_rsrc_t rs, const int (&goff)[SW], unsigned tag, unsigned* abort_word, F&& on_hit) {
     int off[SW];
     u32x4 v[SW];
 #pragma unroll
     for (int u = 0; u < SW; ++u) {
         off[u] = goff[u];
-        got[u] = (u32x4){0u, 0u, 0u, 0u};
         v[u] = pk_gr_poll(rs, off[u]);
     }
     unsigned spins = 0;
@@ -97,9 +98,8 @@ __device__ __forceinline__ bool pk_gr_sweep(__amdgpu_buffer_rsrc_t rs, const int
 #pragma unroll
         for (int u = 0; u < SW; ++u) {
             const bool hit = off[u] != GR_OOB && v[u][3] == tag;
+            if (hit) on_hit(u, v[u]);
             off[u] = hit ? GR_OOB : off[u];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) got[u][e] = hit ? v[u][e] : got[u][e];
             need = need || off[u] != GR_OOB;
         }
         if (__builtin_amdgcn_ballot_w64(need) == 0ull) return true;

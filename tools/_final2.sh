@@ -10,5 +10,5 @@ for w in c2 c4 libri_vgg; do
 done
 timeout -k 10 300 python bench.py --workload c1 --cpu-sample-b 8 > gpurun_out/final_bench_c1.json 2> gpurun_out/final_bench_c1.err || exit 8
 cut -c1-200 gpurun_out/final_bench_c1.json
-LAS_LSTM_NO_XL=1 LAS_DEC_NO_PK=1 LAS_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline 2>gpurun_out/final_rank2.err > gpurun_out/final_rank2.json || { tail gpurun_out/final_rank2.err; exit 9; }
+LAS_LSTM_NO_XL=1 LAS_DEC_NO_PK=1 LAS_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline 2>gpurun_out/final_rank2.err | grep "^{\"metric\"" > gpurun_out/final_rank2.json || { tail gpurun_out/final_rank2.err; exit 9; }
 cut -c1-200 gpurun_out/final_rank2.json

@@ -482,8 +482,10 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                 const float de = de_l[tt];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
+                    // (frames beyond the utterance: the saved s is undefined there -- the forward loop never writes it --, and 0 * NaN
+                    // would poison d q, d f and every gradient behind them; a select, not a product with d e = 0)
                     const float s_ = sv[mt][j][r];
-                    const float dz = de * wev[j] * (1.f - s_ * s_);
+                    const float dz = tt < tcv ? de * wev[j] * (1.f - s_ * s_) : 0.f;
                     dq[j] += dz;
                     const int aa = (wave + PNW * j) * 16 + fr;
                     if (aa < Ap) Du[tt * lda_ + aa] = to_ct<T>(dz * um[mt][j][r]);

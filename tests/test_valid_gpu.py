@@ -139,7 +139,7 @@ def test_resume_reproduces_uninterrupted_run(tmp_path):
         ops.set_precision('bf16')
     assert np.isfinite(first + rest).all()
     np.testing.assert_allclose(rest_b, rest, rtol=1e-6)
-    tol = dict(atol=1e-6, rtol=1e-5)
+    tol = dict(atol=5e-6, rtol=1e-5)        # (split-K float atomics: the last bits depend on arrival order)
     np.testing.assert_allclose(b.asr_model.flat_params.cpu().numpy(), w_a.cpu().numpy(), **tol)
     np.testing.assert_allclose(b.asr_opt.s1.cpu().numpy(), a.asr_opt.s1.cpu().numpy(), **tol)
     np.testing.assert_allclose(b.asr_opt.s2.cpu().numpy(), a.asr_opt.s2.cpu().numpy(), **tol)

@@ -137,14 +137,15 @@ def test_lstm_exchange_variants(ops, monkeypatch, env):
 @pytest.mark.parametrize('T,B,Iin,H,prec', [(25, 100, 16, 64, 'f32'), (19, 130, 16, 320, 'f32'), (15, 300, 8, 256, 'f32'),
                                              (21, 24, 16, 512, 'bf16'), (12, 30, 8, 40, 'f32'), (15, 300, 8, 320, 'bf16'),
                                              (13, 24, 32, 1024, 'bf16'), (7, 24, 4096, 1024, 'bf16'), (9, 40, 16, 1024, 'bf16'),
-                                             (11, 12, 16, 768, 'bf16')])
+                                             (11, 12, 16, 768, 'bf16'), (13, 48, 16, 320, 'bf16'), (10, 200, 8, 160, 'bf16')])
 def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):
     """The launch geometries beyond the C2 shape: many batch slices (B=100), two batch tiles per slice (B=130 at H=320),
     four (B=300 at H=256: LDS-resident weights forward, all-gather backward), H=512 (8-unit workgroups forward, 32 pieces in the
     K-split backward), H not a multiple of 16; H = 1024 (BASELINE configs[4], SURVEY 8d C5: 64 workgroups per direction and batch
     slice, the weight fragments of both kernels fetched from global memory into registers, cross-XCD hand-off; B = 24 as two
     slices of 12, B = 40 as two batch tiles per slice, the 4096-wide concat input of C5's layers 1-2) and H = 768 (zero-padded
-    k-steps of the same kernels).  Against the oracle (torch packed LSTM), ragged lengths; f32 mode where its
+    k-steps of the same kernels); the tagged-granule kernels with two granules per unit (B = 48: slices of 12 rows, three sweep
+    slots per lane) and with two batch tiles per slice (B = 200 at H = 160: slices of 17 rows).  Against the oracle (torch packed LSTM), ragged lengths; f32 mode where its
     LDS-resident f32 weight slab fits (H < ~500 at one batch tile, H <= 256 at four), bf16 mode (8e-2 / 5e-2) otherwise."""
     from oracle import las_ref as R
     rng = np.random.RandomState(T * 1000 + B)

@@ -178,9 +178,15 @@ def main():
         frames = 0
         for i in range(k0, k0 + k):
             x, y, f, hl = staged[i % n_stage]
-            if from_host:                      # the reference's per-step H2D (solver.py:132-133), from pinned memory
-                x, y = (v.to(dev, non_blocking=True) for v in pinned[i % n_stage])
-            t.train_step(x, y, 1.0, host_lens=hl if known_lengths else None)
+            ready = True                       # the staged batches are complete in HBM
+            if from_host:                      # the reference's per-step H2D (solver.py:132-133), from pinned memory,
+                with torch.cuda.stream(ops.copy_stream()):        # on the copy stream as in Trainer.exec
+                    x, y = (v.to(dev, non_blocking=True) for v in pinned[i % n_stage])
+                    ready = torch.cuda.Event()
+                    ready.record(ops.copy_stream())
+                for v in (x, y):
+                    v.record_stream(torch.cuda.current_stream())
+            t.train_step(x, y, 1.0, host_lens=hl if known_lengths else None, inputs_ready=ready)
             frames += f
         return frames
 

@@ -156,6 +156,7 @@ class Seq2Seq(nn.Module):
     def _finish(self, fp, device):
         fp.build(self, device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
+        self.ctc_branch = False          # set by Trainer.train_step for the duration of its forward (see forward())
         self.sample_seed = 0
         self.init_parameters()
 
@@ -242,9 +243,12 @@ class Seq2Seq(nn.Module):
         return beam_decode(self, audio_feature, decode_step, state_len, decode_beam_size)
 
     # -- full forward ----------------------------------------------------------------------------------------
-    def forward(self, audio_feature, decode_step, tf_rate=0.0, teacher=None, state_len=None):
+    def forward(self, audio_feature, decode_step, tf_rate=0.0, teacher=None, state_len=None, state_len_dev=None):
         """reference asr.py:58-112.  Returns (ctc_output [B,T',V]|None, encode_len list[int],
-        att_output [B,L,V]|None, att_maps [ (B,L,T') ]|None)."""
+        att_output [B,L,V]|None, att_maps [ (B,L,T') ]|None).
+        state_len_dev (not in the reference): the int32 device copy of a host list `state_len` when the caller has both
+        (Trainer.train_step) -- building it here from the list is a pageable H2D copy, which makes the host wait for
+        everything queued on the stream, i.e. for the whole previous step."""
         x = audio_feature
         if not x.is_cuda:
             raise ops._lib.LasError('Seq2Seq.forward needs HIP device tensors (no CPU path)')
@@ -256,14 +260,28 @@ class Seq2Seq(nn.Module):
             lens_host = state_len.cpu().tolist()
         else:
             lens_host = [int(v) for v in state_len]
-            lens_dev = torch.tensor(lens_host, dtype=torch.int32, device=x.device)
+            if state_len_dev is not None:
+                lens_dev = state_len_dev.to(device=x.device, dtype=torch.int32)
+            else:
+                lens_dev = torch.tensor(lens_host, dtype=torch.int32, device=x.device)
         T = max(lens_host)                                   # pad_packed_sequence trims to the longest (asr.py:483)
         if T < x.shape[1] and not self.vgg:                  # the VGG front-end convolves over the padding too
             x = x[:, :T].contiguous()
         enc, enc_len_dev, enc_len = self.encode(x.float(), lens_dev, lens_host)
         ctc_output = att_output = att_maps = None
         if self.joint_ctc:
-            ctc_output = ops.linear(enc, self.P('ctc_layer.weight'), self.P('ctc_layer.bias'))
+            if self.ctc_branch and self.joint_att and ops._BRANCH['enabled']:
+                # Trainer.train_step only: the CTC head runs on a stream of its own beside the attend-and-spell loop; the
+                # tensor carries the stream (`_branch`) and ops.joint_loss keeps the CTC loss on it and joins.  Autograd
+                # runs a node's backward on the stream of its forward, so the head's backward stays there as well.
+                cs = ops.branch_stream()
+                ops.fork_to(cs)
+                with torch.cuda.stream(cs):
+                    ctc_output = ops.linear(enc, self.P('ctc_layer.weight'), self.P('ctc_layer.bias'))
+                enc.record_stream(cs)
+                ctc_output._branch = cs
+            else:
+                ctc_output = ops.linear(enc, self.P('ctc_layer.weight'), self.P('ctc_layer.bias'))
         if self.joint_att:
             L = int(decode_step)
             # one coin flip per step for the whole batch (asr.py:96); the flip after step t picks step t+1's input

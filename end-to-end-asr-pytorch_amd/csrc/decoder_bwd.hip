@@ -500,18 +500,26 @@ extern "C" size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* d) { re
 
 static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                            const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
-                           las_dec_bwd_state* bw_, void* stream);
+                           las_dec_bwd_state* bw_, int parts, void* stream);
 
 extern "C" int las_decoder_bwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                                const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
                                las_dec_bwd_state* bw_, void* stream) {
     LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
-    return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, stream);
+    return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, LAS_DEC_BWD_CHAIN | LAS_DEC_BWD_PARAM_SUMS, stream);
+}
+
+extern "C" int las_decoder_bwd_parts(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
+                                     const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
+                                     las_dec_bwd_state* bw_, int parts, void* stream) {
+    LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
+    LAS_CHECK_ARG(parts > 0 && !(parts & ~(LAS_DEC_BWD_CHAIN | LAS_DEC_BWD_PARAM_SUMS)));
+    return decoder_bwd_run(d, p, enc, psi, enc_len, st_, g_htop, bw_, parts, stream);
 }
 
 static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                            const int32_t* enc_len, const las_dec_state* st_, const float* g_htop,
-                           las_dec_bwd_state* bw_, void* stream) {
+                           las_dec_bwd_state* bw_, int parts, void* stream) {
     LAS_CHECK_ARG(d && p && enc && psi && enc_len && st_ && g_htop && bw_);
     const int B = d->B, Tp = d->Tp, E = d->E, A = d->A, C = d->C, NL = d->NL, L = d->L, loc = d->loc, prec = d->prec;
     LAS_CHECK_ARG(B > 0 && Tp > 0 && E > 0 && A > 0 && C > 0 && NL >= 1 && NL <= 4 && L >= 0);
@@ -524,14 +532,17 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     const long acc_stride = las_decoder_loc_acc_floats(A);
     const int AI = (A + 63) / 64;
     if (loc && AI > 8) return LAS_E_UNSUPPORTED;
-    LAS_HIP(hipMemsetAsync(w.dh_carry, 0, sizeof(float) * NL * BC, st));
-    LAS_HIP(hipMemsetAsync(w.dc_carry, 0, sizeof(float) * NL * BC, st));
-    LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
-    if (loc) {
-        LAS_CHECK_ARG(w.df && w.de && w.dpsi && w.acc);
-        LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
-        LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
-        LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
+    const bool chain = parts & LAS_DEC_BWD_CHAIN, sums = parts & LAS_DEC_BWD_PARAM_SUMS;
+    if (loc) LAS_CHECK_ARG(w.df && w.de && w.dpsi && w.acc);
+    if (chain) {
+        LAS_HIP(hipMemsetAsync(w.dh_carry, 0, sizeof(float) * NL * BC, st));
+        LAS_HIP(hipMemsetAsync(w.dc_carry, 0, sizeof(float) * NL * BC, st));
+        LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
+        if (loc) {
+            LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
+            LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
+            LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
+        }
     }
     // [E] dctx | [TC] de | loc: [A] w_e | [10][A] w_lp | [10][TC] f | [8][A] dq partials | [10][201] conv_w | [10][TC+200] df halo
     size_t lds_e = sizeof(float) * (((size_t)E + 3) / 4 * 4 + TC);
@@ -542,11 +553,11 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     const bool drop = d->dropout > 0.f;
     // one persistent launch for the whole sequential chain when the shape / mode allows it and the caller gave the workspace
     const bool pk = w.pk_ws && w.pk_status && las_dec_pk_bwd_ws_bytes(d) > 0;
-    if (pk) {
+    if (pk && chain) {
         int rc = las_dec_pk_bwd(d, p, enc, enc_len, st_, g_htop, bw_, st);
         if (rc) return rc;
     }
-    for (int t = L - 1; t >= 0 && !pk; --t) {
+    for (int t = L - 1; t >= 0 && !pk && chain; --t) {
         // ---- LSTM cells, top layer first
         for (int l = NL - 1; l >= 0; --l) {
             const float* dh_ext = (l == NL - 1) ? g_htop + (long)t * BC : w.d_below;
@@ -633,14 +644,17 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
             if (rc) return rc;
         }
     }
-    if (loc) {
-        // ---- sums over the L steps that are off the sequential chain
+    if (loc && chain) {
+        // ---- sums over the L steps that are off the sequential chain; d psi is the one the encoder's backward waits for
         LocPostArgs q{};
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
         q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
         hipLaunchKernelGGL(att_loc_post, dim3((Tp + POST_TC - 1) / POST_TC, B), dim3(64 * AI), 0, st, q);
         LAS_LAUNCH_OK();
+    }
+    if (!sums) return LAS_OK;
+    if (loc) {
         const long conv_off = ((A * LOC_C + A + 1 + 3) / 4) * 4;
         const int ppb = L < 8 ? L : 8;                                   // (step, utterance) pairs per workgroup
         const long nblk = ((long)L * B + ppb - 1) / ppb;

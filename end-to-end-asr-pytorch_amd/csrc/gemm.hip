@@ -204,12 +204,15 @@ __global__ __launch_bounds__(256) void scale2d_kernel(float beta, int N, float* 
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < N) { float* p = C + (long)blockIdx.y * ldc + c; *p = beta != 0.f ? beta * (*p) : 0.f; }
 }
-__global__ __launch_bounds__(256) void colsum_scale_kernel(float beta, int N, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_scale_kernel(float beta, int N, float* __restrict__ out, float* __restrict__ out2) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < N) out[c] = beta != 0.f ? beta * out[c] : 0.f;
+    if (c < N) {
+        out[c] = beta != 0.f ? beta * out[c] : 0.f;
+        if (out2) out2[c] = beta != 0.f ? beta * out2[c] : 0.f;
+    }
 }
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ld, int M, int N, int rows_per,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, float* __restrict__ out2) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
@@ -224,8 +227,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     }
     part[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (g == 0 && c < N)
-        atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (g == 0 && c < N) {
+        const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        atomicAdd(&out[c], v);
+        if (out2) atomicAdd(&out2[c], v);
+    }
 }
 
 }  // namespace
@@ -261,7 +267,7 @@ static int gemm_common(int prec, int transA, int transB, int M, int N, int K, fl
     static const int swz_env = getenv("LAS_GEMM_NOSWZ") ? 0 : 1;
     if (ksplit > 1) grid.z = ksplit;
     const int swz = swz_env && (long)grid.x * grid.y * grid.z >= 16;
-    if (ksplit > 1) {
+    if (ksplit > 1 && beta != 1.f) {               // (beta = 1: the slices are added to what is there)
         hipLaunchKernelGGL(scale2d_kernel, dim3((N + 255) / 256, M), dim3(256), 0, st, beta, N, C, (long)ldc);
         LAS_LAUNCH_OK();
     }
@@ -301,18 +307,24 @@ extern "C" int las_gemm_ex(int prec, int transA, int transB, int M, int N, int K
                        bias, act, batch, C16, ldc16, stream);
 }
 
-extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {
-    LAS_CHECK_ARG(X && out && M >= 0 && N > 0 && ld >= N);
+extern "C" int las_colsum2(const float* X, int64_t ld, int M, int N, float beta, float* out, float* out2, void* stream) {
+    LAS_CHECK_ARG(X && out && out != out2 && M >= 0 && N > 0 && ld >= N);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, beta, N, out);
-    LAS_LAUNCH_OK();
+    if (beta != 1.f) {                                       // (beta = 1: the sums are added to what is there)
+        hipLaunchKernelGGL(colsum_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, beta, N, out, out2);
+        LAS_LAUNCH_OK();
+    }
     if (M == 0) return LAS_OK;
     const int nx = (N + 63) / 64;
     int slices = (2048 + nx - 1) / nx;                       // ~2048 workgroups in total
     if (slices > (M + 63) / 64) slices = (M + 63) / 64;
     if (slices < 1) slices = 1;
     const int rows_per = ((M + slices - 1) / slices + 3) / 4 * 4;
-    hipLaunchKernelGGL(colsum_kernel, dim3(nx, (M + rows_per - 1) / rows_per), dim3(256), 0, st, X, ld, M, N, rows_per, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nx, (M + rows_per - 1) / rows_per), dim3(256), 0, st, X, ld, M, N, rows_per, out, out2);
     LAS_LAUNCH_OK();
     return LAS_OK;
+}
+
+extern "C" int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream) {
+    return las_colsum2(X, ld, M, N, beta, out, nullptr, stream);
 }

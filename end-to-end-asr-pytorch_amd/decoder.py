@@ -1,6 +1,7 @@
 """Host side of the attend-and-spell decoder loop: ctypes mirrors of las_dec_* (include/las_hip.h) and the
 autograd Function that runs all L steps (and their BPTT) behind two C-ABI calls."""
 import ctypes
+import os
 import torch
 
 from . import _lib, ops
@@ -227,18 +228,43 @@ class DecoderFn(torch.autograd.Function):
             setattr(bw, k, v.data_ptr())
         st = S['_keep'][1]
         g_htop = g_htop.contiguous()
+        tg = {n: ops.wgrad_target(W[n]) for n in names}
+        direct = all(tg[n] is not None for n in names if n not in ('embed.weight', 'char_trans.weight', 'char_trans.bias'))
+        # every parameter offers its gradient buffer: the parameter-only sums over the steps (d conv_w, embedding rows, the
+        # reduction of the per-utterance accumulators) leave the main stream, which goes on with d enc / d psi
+        split = direct and tg['embed.weight'] is not None and not os.environ.get('LAS_NO_DEC_SPLIT')
         with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (A + E), 'byte'):      # enc + saved s (loc) / psi (dot)
-            check(L_.las_decoder_bwd(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
-                                     ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), cur_stream()), 'las_decoder_bwd')
+            check(L_.las_decoder_bwd_parts(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                                           ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), I(1 if split else 3), cur_stream()),
+                  'las_decoder_bwd_parts')
         # ---- contractions over the L steps: one GEMM each; the weight gradients are off the dependency chain and go
         # to the side stream, accumulated into the flat gradient buffer when every parameter offers one
         LB = L * B
         XI = C + E
         g = {}
-        g['embed.weight'] = Bw['demb']
         hs0_prev = S['hs'][0, :L].reshape(LB, C)
-        tg = {n: ops.wgrad_target(W[n]) for n in names}
-        direct = all(tg[n] is not None for n in names if n not in ('embed.weight', 'char_trans.weight', 'char_trans.bias'))
+        off = ((A * 10 + A + 1 + 3) // 4) * 4
+
+        def loc_grads(red):
+            return {'attention.loc_proj.weight': red[:A * 10].view(10, A).t(),
+                    'attention.gen_energy.weight': red[A * 10:A * 10 + A].view(1, A),
+                    'attention.gen_energy.bias': red[A * 10 + A:A * 10 + A + 1],
+                    'attention.loc_conv.weight': red[off:off + 10 * 201].view(10, 1, 201)}
+
+        if split:
+            def param_sums():
+                check(L_.las_decoder_bwd_parts(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
+                                               ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), I(2), cur_stream()),
+                      'las_decoder_bwd_parts')
+                tg['embed.weight'].add_(Bw['demb'])
+                if loc:
+                    red = ops.colsum(Bw['acc'], torch.empty(accf, **f32))
+                    for n, v in loc_grads(red).items():
+                        tg[n].add_(v)
+            ops.on_side_stream(param_sums, [Bw['demb'], Bw['dxin'], Bw.get('df'), Bw.get('acc'), S['att'], S['tok'], enc_len, g_htop],
+                               which=1)
+        else:
+            g['embed.weight'] = Bw['demb']
 
         def dec_wgrads(out, beta):
             ops.gemm(Bw['dq_pre'].view(LB, A), hs0_prev, out['attention.phi.weight'], transA=True, beta=beta)
@@ -249,8 +275,7 @@ class DecoderFn(torch.autograd.Function):
                 h_l = S['hdrop'][l] if (l > 0 and 'hdrop' in S) else S['hs'][l, :L]
                 ops.gemm(dg, x_l, out[f'decoder.layer{l}.weight_ih'], transA=True, beta=beta)
                 ops.gemm(dg, h_l.reshape(LB, C), out[f'decoder.layer{l}.weight_hh'], transA=True, beta=beta)
-                ops.colsum(dg, out[f'decoder.layer{l}.bias_ih'], beta=beta)
-                ops.colsum(dg, out[f'decoder.layer{l}.bias_hh'], beta=beta)
+                ops.colsum(dg, out[f'decoder.layer{l}.bias_ih'], beta=beta, out2=out[f'decoder.layer{l}.bias_hh'])
 
         if direct:
             ops.on_side_stream(lambda: dec_wgrads(tg, 1.0), [Bw['dq_pre'], Bw['dgates'], S['xin'], S['hs']])
@@ -269,13 +294,9 @@ class DecoderFn(torch.autograd.Function):
                  batch=B, sA=Tp, sB=XI, sC=Tp * E)
         if loc:
             d_psi = Bw['dpsi']
-            acc = Bw['acc']
-            red = ops.colsum(acc, torch.empty(accf, **f32))
-            off = ((A * 10 + A + 1 + 3) // 4) * 4
-            g['attention.loc_proj.weight'] = red[:A * 10].view(10, A).t().contiguous()
-            g['attention.gen_energy.weight'] = red[A * 10:A * 10 + A].view(1, A)
-            g['attention.gen_energy.bias'] = red[A * 10 + A:A * 10 + A + 1]
-            g['attention.loc_conv.weight'] = red[off:off + 10 * 201].view(10, 1, 201)
+            if not split:
+                red = ops.colsum(Bw['acc'], torch.empty(accf, **f32))
+                g.update({n: v.contiguous() for n, v in loc_grads(red).items()})
         else:
             d_psi = torch.empty(B, Tp, A, **f32)
             ops.gemm(Bw['de'], S['q'], d_psi, transA=True, M=Tp, N=A, K=L, lda=B * Tp, ldb=B * A, ldc=A, batch=B,

@@ -112,8 +112,8 @@ def backward_with_overlap(loss, model, bucket_elems=64 * 1024 * 1024):
         if not ranges:
             return
         comm.wait_stream(torch.cuda.current_stream())
-        if ops._SIDE['stream'] is not None:
-            comm.wait_stream(ops._SIDE['stream'])
+        for side in ops.side_streams():                       # weight-gradient streams and the CTC branch
+            comm.wait_stream(side)
         with torch.cuda.stream(comm):                         # the collective's stream waits for comm's tail only
             for off, end in ranges:
                 st['works'].append(dist.all_reduce(flat[off:end], op=dist.ReduceOp.SUM, async_op=True))

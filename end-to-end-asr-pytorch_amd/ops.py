@@ -83,7 +83,8 @@ def kernel_timing_summary(records):
 # Weight-gradient GEMMs are off the backward dependency chain, and the persistent LSTM kernels that follow them
 # occupy only ND*ceil(H/16)*slices CUs: run the wgrads on a second HIP stream, accumulating directly into the
 # flat gradient buffer (param.grad views), and join before the optimiser.
-_SIDE = {'enabled': True, 'stream': None, 'dirty': False}
+_SIDE = {'enabled': True, 'stream': None, 'stream1': None, 'dirty': False, 'dirty1': False}
+_BRANCH = {'stream': None, 'enabled': not os.environ.get('LAS_NO_CTC_BRANCH')}
 _GRAD_READY = None      # dist.backward_with_overlap: called with an encoder layer's first gradient view once that layer's
                         # (and therefore every later parameter's) gradients have all been enqueued
 
@@ -92,10 +93,55 @@ def set_wgrad_overlap(flag):
     _SIDE['enabled'] = bool(flag)
 
 
-def _side_stream():
-    if _SIDE['stream'] is None:
-        _SIDE['stream'] = torch.cuda.Stream()
-    return _SIDE['stream']
+_ONE_SIDE = bool(os.environ.get('LAS_ONE_SIDE_STREAM'))      # (A/B measurements: all weight-gradient work on one side stream)
+
+
+def _side_stream(which=0):
+    key = 'stream' if which == 0 or _ONE_SIDE else 'stream1'
+    if _SIDE[key] is None:
+        _SIDE[key] = torch.cuda.Stream()
+    return _SIDE[key]
+
+
+def side_streams():
+    """Every side stream that has been created (dist.py makes the collectives wait for their tails)."""
+    return [s for s in (_SIDE['stream'], _SIDE['stream1'], _BRANCH['stream']) if s is not None]
+
+
+def branch_stream():
+    """The stream of the CTC branch (head GEMM, CTC loss and their backward): it has no consumer before the joint loss /
+    the sum of the d enc contributions, so it runs beside the attend-and-spell loops (Seq2Seq.forward, JointLossFn)."""
+    if _BRANCH['stream'] is None:
+        _BRANCH['stream'] = torch.cuda.Stream()
+    return _BRANCH['stream']
+
+
+def length_stream():
+    """Stream of the per-step length inference + its small D2H (Trainer.train_step(inputs_ready=...))."""
+    if _BRANCH.get('len') is None:
+        _BRANCH['len'] = torch.cuda.Stream()
+    return _BRANCH['len']
+
+
+def copy_stream():
+    """Stream of the per-step H2D copy of the batch (Trainer.exec, bench.py's H2D-inclusive loop)."""
+    if _BRANCH.get('copy') is None:
+        _BRANCH['copy'] = torch.cuda.Stream()
+    return _BRANCH['copy']
+
+
+def fork_to(stream):
+    """`stream` waits for everything enqueued so far on the current stream."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    stream.wait_event(ev)
+
+
+def join_from(stream):
+    """The current stream waits for everything enqueued so far on `stream`."""
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    torch.cuda.current_stream().wait_event(ev)
 
 
 def wgrad_target(p):
@@ -105,29 +151,36 @@ def wgrad_target(p):
     return None
 
 
-def on_side_stream(fn, inputs):
-    """Run fn() on the side stream after everything enqueued so far on the current stream; `inputs` are tensors fn
-    reads (kept alive for the side stream through record_stream)."""
+def on_side_stream(fn, inputs, which=0, after=None):
+    """Run fn() on side stream `which` (0 | 1) after everything enqueued so far on the current stream (and after the
+    event `after`, if given); `inputs` are tensors fn reads (kept alive for the side stream through record_stream).
+    Returns an event recorded on the side stream behind fn()."""
     main = torch.cuda.current_stream()
-    side = _side_stream()
+    side = _side_stream(which)
     ev = torch.cuda.Event()
     ev.record(main)
     with torch.cuda.stream(side):
         side.wait_event(ev)
+        if after is not None:
+            side.wait_event(after)
         fn()
+        done = torch.cuda.Event()
+        done.record(side)
     for t in inputs:
         if t is not None:
             t.record_stream(side)
-    _SIDE['dirty'] = True
+    _SIDE['dirty' if which == 0 or _ONE_SIDE else 'dirty1'] = True
+    return done
 
 
 def join_side_stream():
     """Make the current stream wait for all side-stream work (call before reading gradients)."""
-    if _SIDE['dirty']:
-        ev = torch.cuda.Event()
-        ev.record(_SIDE['stream'])
-        torch.cuda.current_stream().wait_event(ev)
-        _SIDE['dirty'] = False
+    for key, skey in (('dirty', 'stream'), ('dirty1', 'stream1')):
+        if _SIDE[key]:
+            ev = torch.cuda.Event()
+            ev.record(_SIDE[skey])
+            torch.cuda.current_stream().wait_event(ev)
+            _SIDE[key] = False
 
 
 def _ws(nbytes, device):
@@ -307,12 +360,14 @@ def narrow_rows(x, n):
 
 
 
-def colsum(X, out, beta=0.0, M=None, N=None, ld=None):
+def colsum(X, out, beta=0.0, M=None, N=None, ld=None, out2=None):
+    """out = beta*out + column sums of X; out2 (optional) receives the same (bias_ih / bias_hh share their gradient)."""
     L_ = _lib.lib()
     M = X.shape[0] if M is None else M
     N = X.shape[1] if N is None else N
     ld = X.stride(0) if ld is None else ld
-    check(L_.las_colsum(P(X.data_ptr()), LL(ld), I(M), I(N), F(beta), P(out.data_ptr()), cur_stream()), 'las_colsum')
+    check(L_.las_colsum2(P(X.data_ptr()), LL(ld), I(M), I(N), F(beta), P(out.data_ptr()),
+                         P(out2.data_ptr()) if out2 is not None else None, cur_stream()), 'las_colsum2')
     return out
 
 
@@ -480,36 +535,65 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
               'las_lstm_rec_bwd')
     x2 = x.view(T * B, Iin)
     hf2 = hf.view(T * B, ND * H)
-    # bf16 twins of the GEMM operands of this layer's backward (one cast pass each: 6 bytes per element, HBM-bound; the
-    # three GEMMs that read d gates then move half the bytes and convert nothing while staging)
-    dgf16 = twin(dgf, make=True)
-    hf16 = twin(hf2, make=True) if dgf16 is not None else None
 
-    def wgrads(gw_ih, gw_hh, gb_ih, gb_hh, beta):
-        gemm(dgf, x2, gw_ih, transA=True, beta=beta, A16=dgf16, B16=x16)        # [ND*4H, I]
-        colsum(dgf, gb_ih, beta=beta)
-        if gb_hh is not None:
-            colsum(dgf, gb_hh, beta=beta)
-        for d in range(ND):
-            if T > 1:
-                if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
-                    sa, sb = (slice(B, None), slice(d * H4, (d + 1) * H4)), (slice(0, (T - 1) * B), slice(d * H, (d + 1) * H))
-                else:           # sum_{t<=T-2} dg[t]^T h[t+1]
-                    sa, sb = (slice(0, (T - 1) * B), slice(d * H4, (d + 1) * H4)), (slice(B, None), slice(d * H, (d + 1) * H))
-                two = dgf16 is not None and hf16 is not None
-                gemm(dgf[sa], hf2[sb], gw_hh[d], transA=True, beta=beta, A16=dgf16[sa] if two else None, B16=hf16[sb] if two else None)
-            elif beta == 0.0:
-                gw_hh[d].zero_()
+    def w_hh_grad(d, gw_hh, beta, d16, h16):
+        if T > 1:
+            if d == 0:      # sum_{t>=1} dg[t]^T h[t-1]
+                sa, sb = (slice(B, None), slice(d * H4, (d + 1) * H4)), (slice(0, (T - 1) * B), slice(d * H, (d + 1) * H))
+            else:           # sum_{t<=T-2} dg[t]^T h[t+1]
+                sa, sb = (slice(0, (T - 1) * B), slice(d * H4, (d + 1) * H4)), (slice(B, None), slice(d * H, (d + 1) * H))
+            two = d16 is not None and h16 is not None
+            gemm(dgf[sa], hf2[sb], gw_hh[d], transA=True, beta=beta, A16=d16[sa] if two else None, B16=h16[sb] if two else None)
+        elif beta == 0.0:
+            gw_hh[d].zero_()
 
     if targets is not None:
-        on_side_stream(lambda: wgrads(targets[0], targets[1], targets[2], targets[3], 1.0), [dgf, x, hf, dgf16, hf16, x16])
+        # The weight gradients are accumulated into the flat gradient buffer on TWO side streams (the main stream goes on
+        # with d x and the layer below).  bf16 twins of the GEMM operands: one cast pass each (6 bytes per element,
+        # HBM-bound), after which the three GEMMs that read d gates move half the bytes and convert nothing while staging;
+        # only the twin the d x GEMM needs is made on the main stream.
+        #   side 1: hf's twin | bias sums (ONE pass for bias_ih and bias_hh) | dW_hh of the reverse direction
+        #   side 0: d gates' twin (bottom layer: nobody else needs it) | dW_ih | dW_hh of the forward direction
+        gw_ih, gw_hh, gb_ih, gb_hh = targets
+        dgf16 = twin(dgf, make=True) if need_gx else None
         gx = gemm(dgf, w_ih, A16=dgf16, B16=w_ih16).view(T, B, Iin) if need_gx else None
+        s0, s1 = _side_stream(0), _side_stream(1)
+        box = {}
+
+        def part1():
+            box['hf16'] = twin(hf2, make=True)
+            box['e_hf'] = torch.cuda.Event()
+            box['e_hf'].record(s1)
+            colsum(dgf, gb_ih, beta=1.0, out2=gb_hh)
+
+        def part0():
+            box['d16'] = dgf16 if dgf16 is not None else twin(dgf, make=True)
+            box['e_d16'] = torch.cuda.Event()
+            box['e_d16'].record(s0)
+            gemm(dgf, x2, gw_ih, transA=True, beta=1.0, A16=box['d16'], B16=x16)        # [ND*4H, I]
+            s0.wait_event(box['e_hf'])
+            w_hh_grad(0, gw_hh, 1.0, box['d16'], box['hf16'])
+
+        def part1b():
+            s1.wait_event(box['e_d16'])
+            for d in range(1, ND):
+                w_hh_grad(d, gw_hh, 1.0, box['d16'], box['hf16'])
+
+        on_side_stream(part1, [dgf, hf], which=1)
+        on_side_stream(part0, [dgf, x, hf, dgf16, x16, box['hf16']], which=0)
+        if ND > 1:
+            on_side_stream(part1b, [dgf, hf, box['d16'], box['hf16']], which=1)
         return gx, None, None, None
+    dgf16 = twin(dgf, make=True)
+    hf16 = twin(hf2, make=True) if dgf16 is not None else None
     gx = gemm(dgf, w_ih, A16=dgf16, B16=w_ih16).view(T, B, Iin) if need_gx else None
     gw_ih = torch.empty(ND * H4, Iin, dtype=torch.float32, device=dev)
     gw_hh = torch.empty_like(w_hh)
     gb = torch.empty(ND * H4, dtype=torch.float32, device=dev)
-    wgrads(gw_ih, gw_hh, gb, None, 0.0)
+    gemm(dgf, x2, gw_ih, transA=True, beta=0.0, A16=dgf16, B16=x16)        # [ND*4H, I]
+    colsum(dgf, gb, beta=0.0)
+    for d in range(ND):
+        w_hh_grad(d, gw_hh, 0.0, dgf16, hf16)
     return gx, gw_ih, gw_hh, gb
 
 
@@ -593,13 +677,26 @@ class JointLossFn(torch.autograd.Function):
             rowloss = torch.empty(B * Lx, **f32)
             check(L_.las_ce_loss(ptr(att_pred), ptr(y), I(y.shape[1]), ptr(ntok), I(B), I(Lx), I(V), F(1.0 - w),
                                  ptr(rowloss), ptr(att), ptr(datt), cur_stream()), 'las_ce_loss')
+        cs = getattr(ctc_pred, '_branch', None) if ctc_pred is not None else None
+        ctx.branch = cs
         if ctc_pred is not None:
-            label = y[:, 1:L + 1].contiguous()
-            nll, la, ctc_ctx = _ctc_fwd(ctc_pred.contiguous(), label, enc_len, ntok, 0)
-            ctc = torch.empty(1, **f32)
-            check(L_.las_norm_mean_fwd(ptr(nll), ptr(ntok), I(nll.shape[0]), ptr(ctc), cur_stream()), 'las_norm_mean_fwd')
-            ctx.ctc = ctc_ctx
-            ctx.log_alpha = la
+            def ctc_part():
+                label = y[:, 1:L + 1].contiguous()
+                nll, la, ctc_ctx = _ctc_fwd(ctc_pred.contiguous(), label, enc_len, ntok, 0)
+                c = torch.empty(1, **f32)
+                check(L_.las_norm_mean_fwd(ptr(nll), ptr(ntok), I(nll.shape[0]), ptr(c), cur_stream()), 'las_norm_mean_fwd')
+                return c, la, ctc_ctx
+            if cs is None:
+                ctc, ctx.log_alpha, ctx.ctc = ctc_part()
+            else:
+                # The CTC branch (Seq2Seq.forward): its stream forked from the main one after enc / the label counts were
+                # enqueued and before the attend-and-spell loop, so the loss runs beside that loop; joined here.
+                with torch.cuda.stream(cs):
+                    ctc, ctx.log_alpha, ctx.ctc = ctc_part()
+                for t_ in (y, ntok, enc_len):
+                    t_.record_stream(cs)
+                join_from(cs)
+                ctc.record_stream(torch.cuda.current_stream())
         total = torch.empty(1, **f32)
         check(L_.las_combine2(ptr(att), F(1.0 - w), ptr(ctc), F(w), ptr(total), cur_stream()), 'las_combine2')
         ctx.datt, ctx.ntok, ctx.w = datt, ntok, w
@@ -613,14 +710,22 @@ class JointLossFn(torch.autograd.Function):
         L_ = _lib.lib()
         g = g.contiguous().view(1).float()
         gatt = gctc = None
+        if ctx.ctc is not None:
+            def ctc_part():
+                B = ctx.ntok.shape[0]
+                gs = torch.empty(B, dtype=torch.float32, device=g.device)
+                check(L_.las_norm_mean_bwd(ptr(g), F(ctx.w), ptr(ctx.ntok), I(B), ptr(gs), cur_stream()), 'las_norm_mean_bwd')
+                return _ctc_bwd(ctx.ctc, gs)
+            if ctx.branch is None:
+                gctc = ctc_part()
+            else:                       # beside the decoder's BPTT: its consumer (the head's backward) runs on the same stream
+                fork_to(ctx.branch)
+                with torch.cuda.stream(ctx.branch):
+                    gctc = ctc_part()
+                g.record_stream(ctx.branch)
         if ctx.datt is not None:
             gatt = ctx.datt
             check(L_.las_scale_dev(ptr(gatt), LL(gatt.numel()), ptr(g), cur_stream()), 'las_scale_dev')
-        if ctx.ctc is not None:
-            B = ctx.ntok.shape[0]
-            gs = torch.empty(B, dtype=torch.float32, device=g.device)
-            check(L_.las_norm_mean_bwd(ptr(g), F(ctx.w), ptr(ctx.ntok), I(B), ptr(gs), cur_stream()), 'las_norm_mean_bwd')
-            gctc = _ctc_bwd(ctx.ctc, gs)
         ctx.datt = ctx.ctc = None
         return gatt, gctc, None, None, None, None, None
 

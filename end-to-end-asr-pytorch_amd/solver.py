@@ -141,27 +141,53 @@ class Trainer(Solver):
         self.asr_model.sync_bf16()
 
     # ------------------------------------------------------------------------------------------------ one step
-    def train_step(self, x, y, tf_rate, host_lens=None, shard_weight=1.0):
+    def train_step(self, x, y, tf_rate, host_lens=None, shard_weight=1.0, inputs_ready=None):
         """The body of the reference's training loop, solver.py:127-182.  x (B,T,D) / y (B,L+2) on the device.
         Returns device scalars (loss, att, ctc) and the predictions; nothing here waits on the GPU except the
         single small read-back of lengths.  `host_lens=(state_len, ans_len)` skips that read-back when the caller
         already knows the lengths on the host (bench.py's kernel-timing pass uses it so that no event bracket
         contains a host bubble; the timed region of the benchmark does NOT).  `shard_weight` = B_local * world /
         B_global (1 for equal shards): both losses are batch means, so the global-batch gradient is the B_local-weighted
-        mean of the ranks' gradients."""
+        mean of the ranks' gradients.
+        `inputs_ready`: None = x / y were produced on the current stream, so the length inference and its read-back
+        queue up behind everything on it (the previous step included).  True (x / y are complete) or a torch.cuda.Event
+        recorded behind their producer (an H2D copy on another stream, `exec`): the length inference and the read-back
+        run on a stream of their own, the host does not wait for the previous step's tail and enqueues this step's
+        kernels while that one still runs -- the step has no host bubble at its start."""
         if x.shape[0] == 0:                                       # a bucket smaller than the world: nothing on this rank,
             ldist.allreduce_grads(self.asr_model.flat_grads)      # but it still joins the exchange and the (global) update
             self.asr_opt.step(zero_grad=True)
             z = torch.zeros((), device=self.device)
             return z, z, z, None, 0
-        lens = ops.infer_lengths(x)                               # solver.py:134, on the device
-        ntok = ops.count_nonzero(y)                               # solver.py:136,159
-        if host_lens is None:
-            host = torch.cat([lens, ntok.max().view(1)]).cpu().tolist()  # the one D2H sync of the step
+        if inputs_ready is not None and inputs_ready is not True:
+            torch.cuda.current_stream().wait_event(inputs_ready)
+        if inputs_ready is not None and host_lens is None and not os.environ.get('LAS_NO_LEN_STREAM'):
+            ls = ops.length_stream()
+            if inputs_ready is not True:
+                ls.wait_event(inputs_ready)
+            with torch.cuda.stream(ls):
+                lens = ops.infer_lengths(x)                           # solver.py:134, on the device
+                ntok = ops.count_nonzero(y)                           # solver.py:136,159
+                host = torch.cat([lens, ntok.max().view(1)]).cpu().tolist()  # the one D2H sync of the step (this stream only)
+            for t_ in (lens, ntok):                                   # complete (the host has waited for them)
+                t_.record_stream(torch.cuda.current_stream())
+            for t_ in (x, y):
+                t_.record_stream(ls)
             state_len, ans_len = host[:-1], int(host[-1])
         else:
-            state_len, ans_len = list(host_lens[0]), int(host_lens[1])
-        ctc_pred, enc_len, att_pred, _ = self.asr_model(x, ans_len, tf_rate=tf_rate, teacher=y, state_len=state_len)
+            lens = ops.infer_lengths(x)                               # solver.py:134, on the device
+            ntok = ops.count_nonzero(y)                               # solver.py:136,159
+            if host_lens is None:
+                host = torch.cat([lens, ntok.max().view(1)]).cpu().tolist()  # the one D2H sync of the step
+                state_len, ans_len = host[:-1], int(host[-1])
+            else:
+                state_len, ans_len = list(host_lens[0]), int(host_lens[1])
+        self.asr_model.ctc_branch = True                          # CTC head + loss beside the attend-and-spell loops (ops.branch_stream)
+        try:
+            ctc_pred, enc_len, att_pred, _ = self.asr_model(x, ans_len, tf_rate=tf_rate, teacher=y, state_len=state_len,
+                                                             state_len_dev=lens)
+        finally:
+            self.asr_model.ctc_branch = False
         loss, att_loss, ctc_loss = ops.joint_loss(att_pred, ctc_pred, y, ntok, self.asr_model.last_enc_len_dev, ans_len,
                                                   self.ctc_weight)
         ldist.backward_with_overlap(loss if shard_weight == 1.0 else loss * shard_weight, self.asr_model)   # solver.py:177
@@ -177,10 +203,20 @@ class Trainer(Solver):
                 tf_rate = self.tf_start - self.step * (self.tf_start - self.tf_end) / self.max_step
                 assert len(x.shape) == 4, 'Bucketing should cause acoustic feature to have shape 1xBxTxD'
                 assert len(y.shape) == 3, 'Bucketing should cause label have to shape 1xBxT'
-                x = x.squeeze(0).to(device=self.device, dtype=torch.float32, non_blocking=True)
-                y = y.squeeze(0).to(device=self.device, dtype=torch.long, non_blocking=True)
+                ready = None
+                if self.device.type == 'cuda':                   # H2D on a copy stream: not queued behind the previous step
+                    with torch.cuda.stream(ops.copy_stream()):
+                        x = x.squeeze(0).to(device=self.device, dtype=torch.float32, non_blocking=True)
+                        y = y.squeeze(0).to(device=self.device, dtype=torch.long, non_blocking=True)
+                        ready = torch.cuda.Event()
+                        ready.record(ops.copy_stream())
+                    for t_ in (x, y):
+                        t_.record_stream(torch.cuda.current_stream())
+                else:
+                    x = x.squeeze(0).to(device=self.device, dtype=torch.float32, non_blocking=True)
+                    y = y.squeeze(0).to(device=self.device, dtype=torch.long, non_blocking=True)
                 gB = getattr(self.train_set, 'last_global_B', None) or int(x.shape[0]) * self.world
-                loss, att_loss, ctc_loss, att_pred, ans_len = self.train_step(x, y, tf_rate,
+                loss, att_loss, ctc_loss, att_pred, ans_len = self.train_step(x, y, tf_rate, inputs_ready=ready,
                                                                               shard_weight=int(x.shape[0]) * self.world / gB)
                 self._log_train(loss, att_loss, ctc_loss, att_pred, y, ans_len)
                 if self.step % self.valid_step == 0:

@@ -62,6 +62,9 @@ int las_gemm_ex(int prec, int transA, int transB, int M, int N, int K, float alp
                 int64_t strideC, const float* bias, int act, int batch, void* C16, int64_t ldc16, void* stream);
 /* out[n] = beta*out[n] + sum_m X[m,n]  (bias gradients of the layers above). */
 int las_colsum(const float* X, int64_t ld, int M, int N, float beta, float* out, void* stream);
+/* The same sums added to TWO vectors in one pass over X (out2 may be NULL): nn.LSTM's / nn.LSTMCell's bias_ih and bias_hh
+ * receive the same gradient (src/asr.py:473, :330). */
+int las_colsum2(const float* X, int64_t ld, int M, int N, float beta, float* out, float* out2, void* stream);
 
 /* ---- Persistent (Bi)LSTM recurrence, time-major -------------------------------------------------
  * Replaces the sequential half of nn.LSTM(bidirectional, batch_first, packed) and its BPTT at
@@ -208,6 +211,16 @@ int las_decoder_att_chunks(int Tp);
 int las_decoder_bwd(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,
                     const int32_t* enc_len, const las_dec_state* state, const float* g_htop,
                     las_dec_bwd_state* bwd, void* stream);
+/* The same call in two parts, for a caller that keeps the parameter-only sums off its critical path (a second stream):
+ *   LAS_DEC_BWD_CHAIN       the zero fills, the BPTT chain and att_loc_post (d psi, d w_lp, d w_e, d b_e into acc): everything
+ *                           the encoder's backward waits for;
+ *   LAS_DEC_BWD_PARAM_SUMS  d conv_w (into acc, behind the chain's zero fill) and the embedding rows demb: parameters only.
+ * PARAM_SUMS reads what CHAIN wrote (df, dxin): enqueue it behind CHAIN.  las_decoder_bwd = both, in this order. */
+#define LAS_DEC_BWD_CHAIN 1
+#define LAS_DEC_BWD_PARAM_SUMS 2
+int las_decoder_bwd_parts(const las_dec_dims* dims, const las_dec_params* params, const float* enc, const float* psi,
+                          const int32_t* enc_len, const las_dec_state* state, const float* g_htop, las_dec_bwd_state* bw,
+                          int parts, void* stream);
 
 /* out[c][r] = in[r][c] (weight transposes for the backward skinny products) */
 int las_transpose2d(const float* in, float* out, int R, int C, void* stream);

@@ -421,6 +421,188 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
     }
 }
 
+// The same sums on the matrix cores (bf16 mode).  Workgroup = (utterance b, 16 frames), wave w owns the attention-dim tiles
+// j = w + NW*i (16 dims each): per step and tile
+//   u   = F [16 frames x 10 channels] * W_lp^T      one 16x16x16 MFMA; a lane gets rows (frames) 4g..4g+3 of column a
+//   dz  = de[t] * w_e[a] * (1 - s^2),  d psi += dz,  d w_e += de[t] * s,  du = dz * (1 - tanh(u)^2)     (~12 VALU per element
+//         instead of ~46: no broadcasts, no 10-term products)
+//   d W_lp^T [10 x 16] += F^T [10 x 16 frames] * du   one MFMA: du in its OUTPUT layout (column a, four consecutive frames)
+//         is exactly the B operand of a product that contracts over the frames -- no trip through LDS.
+// The saved s is read once, as 64-byte row segments, two steps in flight per wave; nothing is shared between waves (no LDS,
+// no barrier).  Frames beyond the utterance are masked by SELECTS (s, f there are undefined).
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+template <int NT>
+__global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
+    const int b = blockIdx.y, t0 = blockIdx.x * 16, len = a.lens[b];
+    if (t0 >= len) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fr = lane & 15, g = lane >> 4;
+    const int A = a.A, Tp = a.Tp, ntiles = (A + 15) / 16;
+    bool okc[NT];
+    int corr[NT];                        // byte correction that keeps a column beyond A (last tile) inside its row
+    float we_r[NT];
+    bf16x4 wlpB[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int acol = (wave + NW * i) * 16 + fr;
+        okc[i] = acol < A;
+        const int ac = min(acol, A - 1);
+        corr[i] = (ac - acol) * 4;
+        we_r[i] = okc[i] ? a.w_e[ac] : 0.f;
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * g + r;
+            w[r] = (okc[i] && c < LOC_C) ? a.w_lp[ac * LOC_C + min(c, LOC_C - 1)] : 0.f;
+        }
+        const unsigned lo = pack_bf16x2(w[0], w[1]), hi = pack_bf16x2(w[2], w[3]);
+        wlpB[i] = bf16x4{(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
+    }
+    bool tv[4];
+    int voff_s[4], off_fu[4];                           // byte offsets inside the step's slab of utterance b
+    bool v_fu[4], v_fw[4];
+    // de and the d W_lp operand are four CONSECUTIVE frames: one 16-byte load each (frames beyond the utterance are
+    // masked, beyond the slab the buffer returns zero)
+    const int off_e = (t0 + 4 * g) * 4, off_fw = (min(fr, LOC_C - 1) * Tp + t0 + 4 * g) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * g + r;
+        tv[r] = t < len;
+        const int tc = min(t, len - 1);
+        voff_s[r] = (tc * A + wave * 16 + fr) * 4;      // tile i: + i * NW * 64 bytes (wave-uniform: the scalar offset)
+        // u operand: lane (m = frame t0 + fr, k = channel 4g + r)
+        const int c = 4 * g + r, tf = t0 + fr;
+        v_fu[r] = c < LOC_C && tf < len;
+        off_fu[r] = (min(c, LOC_C - 1) * Tp + min(tf, len - 1)) * 4;
+        // d W_lp operand: lane (m = channel fr, k = frame t0 + 4g + r)
+        v_fw[r] = fr < LOC_C && tv[r];
+    }
+    const long step_s = (long)a.B * Tp * A, step_f = (long)a.B * LOC_C * Tp, step_e = (long)a.B * Tp;
+    const float* __restrict__ sb = a.s + (long)b * Tp * A;
+    const float* __restrict__ fb = a.f + (long)b * LOC_C * Tp;
+    const float* __restrict__ eb = a.de + (long)b * Tp;
+    const int nt_w = (ntiles - wave + NW - 1) / NW;           // tiles this wave really has (wave-uniform)
+
+    // One buffer resource per step and tensor (scalar work), 32-bit lane offsets: the 4*NT loads of a step share four
+    // offset registers.  Every s element a lane reads is a DEFINED one (rows clamped to the utterance's last frame, columns
+    // to A - 1), so s needs no select: the masked de / w_e make its terms exact zeros.
+    struct Set { float s[NT][4]; float de[4], fu[4], fw[4]; };
+    auto load = [&](Set& q, int l) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sb + l * step_s), 0, Tp * A * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + l * step_f), 0, LOC_C * Tp * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(eb + l * step_e), 0, Tp * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (i < nt_w) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    q.s[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff_s[r] + corr[i], i * NW * 64, 0));
+            }
+        const u32x4 ve = __builtin_amdgcn_raw_buffer_load_b128(re, off_e, 0, 0);
+        const u32x4 vw = __builtin_amdgcn_raw_buffer_load_b128(rf, off_fw, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            q.de[r] = __uint_as_float(ve[r]);
+            q.fw[r] = __uint_as_float(vw[r]);
+            q.fu[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, off_fu[r], 0, 0));
+        }
+    };
+    float dps[NT][4], dwe[NT], dbe = 0.f;
+    f32x4 dW[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        dwe[i] = 0.f;
+        dW[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dps[i][r] = 0.f;
+    }
+    auto pack4 = [](float x0, float x1, float x2, float x3) {
+        const unsigned lo = pack_bf16x2(x0, x1), hi = pack_bf16x2(x2, x3);
+        return bf16x4{(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
+    };
+    auto compute = [&](const Set& q) {
+        float de[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { de[r] = tv[r] ? q.de[r] : 0.f; dbe += de[r]; }
+        const bf16x4 fu = pack4(v_fu[0] ? q.fu[0] : 0.f, v_fu[1] ? q.fu[1] : 0.f, v_fu[2] ? q.fu[2] : 0.f, v_fu[3] ? q.fu[3] : 0.f);
+        const bf16x4 fw = pack4(v_fw[0] ? q.fw[0] : 0.f, v_fw[1] ? q.fw[1] : 0.f, v_fw[2] ? q.fw[2] : 0.f, v_fw[3] ? q.fw[3] : 0.f);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (i < nt_w) {
+                const f32x4 u = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fu, wlpB[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                float du[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s_ = q.s[i][r];
+                    const float th = fast_tanh(u[r]);          // (rows beyond the utterance: F = 0 there, u = 0)
+                    const float dz = de[r] * we_r[i] * (1.f - s_ * s_);
+                    dps[i][r] += dz;
+                    dwe[i] = fmaf(de[r], s_, dwe[i]);
+                    du[r] = dz * (1.f - th * th);
+                }
+                dW[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fw, pack4(du[0], du[1], du[2], du[3]), dW[i], 0, 0, 0);
+            }
+    };
+    // three register sets: a step's rows are requested two steps before they are used (one step ahead left every step
+    // waiting out most of the HBM latency: 497 us; a step's arithmetic is ~0.6 us)
+    // Steps behind the utterance's last label carry no gradient (d e = 0 exactly: the loss ignores them and nothing flows
+    // back from later steps), and labels are ragged: find the last step with a nonzero d e in this workgroup's frames
+    // (lane l checks steps l, l + 64, ...) and stop there.
+    int lmax = -1;
+    for (int l = lane; l < a.L; l += 64) {
+        const float* __restrict__ el = eb + l * step_e + t0;
+        bool nz = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) nz |= (t0 + k < len) && (el[min(k, len - 1 - t0)] != 0.f);
+        if (nz) lmax = l;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) lmax = max(lmax, __shfl_xor(lmax, m));
+    // gridDim.z workgroups share the steps of one (utterance, frame tile) in contiguous runs (d psi is ADDED to the
+    // caller-zeroed buffer): the ragged step counts would otherwise leave the kernel waiting for its longest workgroups
+    const int Lall = __builtin_amdgcn_readfirstlane(lmax + 1);
+    const int per = (Lall + (int)gridDim.z - 1) / (int)gridDim.z, lb = (int)blockIdx.z * per, L = min(Lall, lb + per);
+    if (lb >= L) return;
+    Set q0, q1, q2;
+    load(q0, lb);
+    if (lb + 1 < L) load(q1, lb + 1);
+    for (int l = lb; l < L; l += 3) {
+        if (l + 2 < L) load(q2, l + 2);
+        compute(q0);
+        if (l + 1 < L) {
+            if (l + 3 < L) load(q0, l + 3);
+            compute(q1);
+        }
+        if (l + 2 < L) {
+            if (l + 4 < L) load(q1, l + 4);
+            compute(q2);
+        }
+    }
+    float* accg = a.acc + (long)b * a.acc_stride;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+        if (i < nt_w) {
+            const int acol = (wave + NW * i) * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (okc[i] && tv[r]) atomicAdd(&a.dpsi[((long)b * Tp + t0 + 4 * g + r) * A + acol], dps[i][r]);
+            float v = dwe[i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0 && okc[i]) atomicAdd(&accg[A * LOC_C + acol], v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * g + r;
+                if (okc[i] && c < LOC_C) atomicAdd(&accg[c * A + acol], dW[i][r]);
+            }
+        }
+    if (wave == 0) {                       // every lane of a 16-lane row holds the same four frames
+        float v = dbe;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 0) atomicAdd(&accg[A * LOC_C + A], v);
+    }
+}
+
 // d conv_w[c][k] += sum over this block's (step, utterance) pairs of  sum_t df[c][t] * prev[t + k - K].
 // Thread = (c, 10 consecutive k): a sliding register window over prev gives 10 FMAs per two LDS reads.
 constexpr int CW_KPT = 10, CW_GROUPS = (LOC_W + CW_KPT - 1) / CW_KPT;       // 21 groups x 10 channels = 210 threads
@@ -650,7 +832,20 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
         q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
-        hipLaunchKernelGGL(att_loc_post, dim3((Tp + POST_TC - 1) / POST_TC, B), dim3(64 * AI), 0, st, q);
+        static const int no_mma = getenv("LAS_LOC_POST_VALU") ? 1 : 0;          // (A/B measurements)
+        if (prec == LAS_PREC_BF16 && !no_mma) {
+            const int ntiles = (A + 15) / 16, NW = ntiles <= 20 ? 4 : 8, NT = (ntiles + NW - 1) / NW;
+            const dim3 grid((Tp + 15) / 16, B, L >= 48 ? 3 : 1), blk(64 * NW);
+            switch (NT) {
+                case 1: hipLaunchKernelGGL(att_loc_post_mma<1>, grid, blk, 0, st, q, NW); break;
+                case 2: hipLaunchKernelGGL(att_loc_post_mma<2>, grid, blk, 0, st, q, NW); break;
+                case 3: hipLaunchKernelGGL(att_loc_post_mma<3>, grid, blk, 0, st, q, NW); break;
+                case 4: hipLaunchKernelGGL(att_loc_post_mma<4>, grid, blk, 0, st, q, NW); break;
+                default: hipLaunchKernelGGL(att_loc_post_mma<5>, grid, blk, 0, st, q, NW); break;
+            }
+        } else {
+            hipLaunchKernelGGL(att_loc_post, dim3((Tp + POST_TC - 1) / POST_TC, B), dim3(64 * AI), 0, st, q);
+        }
         LAS_LAUNCH_OK();
     }
     if (!sums) return LAS_OK;

@@ -566,12 +566,14 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
             box['e_hf'].record(s1)
             colsum(dgf, gb_ih, beta=1.0, out2=gb_hh)
 
-        def part0():
+        def part0a():
             box['d16'] = dgf16 if dgf16 is not None else twin(dgf, make=True)
             box['e_d16'] = torch.cuda.Event()
-            box['e_d16'].record(s0)
+            box['e_d16'].record(torch.cuda.current_stream())
+
+        def part0b():
             gemm(dgf, x2, gw_ih, transA=True, beta=1.0, A16=box['d16'], B16=x16)        # [ND*4H, I]
-            s0.wait_event(box['e_hf'])
+            torch.cuda.current_stream().wait_event(box['e_hf'])
             w_hh_grad(0, gw_hh, 1.0, box['d16'], box['hf16'])
 
         def part1b():
@@ -580,9 +582,20 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
                 w_hh_grad(d, gw_hh, 1.0, box['d16'], box['hf16'])
 
         on_side_stream(part1, [dgf, hf], which=1)
-        on_side_stream(part0, [dgf, x, hf, dgf16, x16, box['hf16']], which=0)
-        if ND > 1:
-            on_side_stream(part1b, [dgf, hf, box['d16'], box['hf16']], which=1)
+        if need_gx:
+            on_side_stream(lambda: (part0a(), part0b()), [dgf, x, hf, dgf16, x16, box['hf16']], which=0)
+            if ND > 1:
+                on_side_stream(part1b, [dgf, hf, box['d16'], box['hf16']], which=1)
+        else:
+            # bottom layer: nothing is left for the main stream, and the side streams share ONE hardware queue (their
+            # kernels run one after the other): its half of the weight gradients runs on the main stream itself, so
+            # the step's tail is two queues wide
+            part0a()
+            if ND > 1:
+                on_side_stream(part1b, [dgf, hf, box['d16'], box['hf16']], which=1)
+            part0b()
+            if box['hf16'] is not None:
+                box['hf16'].record_stream(torch.cuda.current_stream())
         return gx, None, None, None
     dgf16 = twin(dgf, make=True)
     hf16 = twin(hf2, make=True) if dgf16 is not None else None

@@ -257,8 +257,11 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     T* Wt = (T*)(flag + 4);                                      // [NTW*128][LDK] W_lp rows (a x channels) for u = tanh(W_lp f)
     T* WlT = Wt + NTW * PNW * 16 * LDK;                          // [16][lda_] W_lp^T rows (channel x a) for d f = d u W_lp
     T* Ft = WlT + 16 * lda_;                                     // [MT*16][LDK] f of my frames
-    char* scratch = (char*)(Ft + MT * 16 * LDK);                 // phase A: d f window + conv partials; phase E: d u tile
-    float* dfn_l = (float*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);       // [10][WN]
+    // phase A: d f window + conv partials; phase E: d u tile.  The 16-byte alignment is applied to the OFFSET from smem: a
+    // pointer rounded through uintptr_t loses its LDS address space, and every access through it (the conv loop's window
+    // reads, the piece sums, the d u tile) compiled to FLAT loads / stores -- 11 000 cycles for the conv loop alone
+    const size_t scratch_off = ((size_t)((char*)(Ft + MT * 16 * LDK) - smem) + 15) & ~(size_t)15;
+    float* dfn_l = (float*)(smem + scratch_off);                 // [10][WN]
     float* f4_l = dfn_l + LOC_C * WN;                            // [NSEG][10][TCq][4]
     T* Du = (T*)dfn_l;                                           // [MT*16][lda_]   (aliases the two above)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
@@ -357,6 +360,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                 }
                 *(float4*)(f4_l + (size_t)i * 4) = make_float4(o0, o1, o2, o3);
             }
+            PK_STAMP(17);
             __syncthreads();
             float cpart = 0.f;
             if (threadIdx.x < 4 * TC) {                       // thread = (frame, tap segment): its 10 channel partials
@@ -369,6 +373,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             if (threadIdx.x < 4 * TC && (threadIdx.x & 3) == 3) ct_l[threadIdx.x >> 2] = cpart;
         }
         __syncthreads();
+        PK_STAMP(18);
         load_s(t);                      // in flight during the u recompute and the wait for the pieces; first used in phase E
         PK_STAMP(0);
         // 1 - u^2 of my elements (u = tanh(F W_lp^T) on the MFMA), kept in registers

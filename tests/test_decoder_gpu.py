@@ -304,3 +304,57 @@ def test_persistent_bptt_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L)
             continue            # d b_e = sum of d e, which the softmax makes cancel to 0: what is left is rounding, not signal
                                 # (the per-step path's `dot` from the saved context leaves 2e-2 at the C2 shape, this one 2e-6)
         assert np.abs(got - ref).max() <= lim, (k, float(np.abs(got - ref).max()), float(lim))
+
+
+@pytest.mark.parametrize('B,Tp,E,A,C,V,L', [(5, 150, 48, 40, 32, 31, 6),        # one tile per wave, no step split
+                                            (4, 40, 32, 512, 32, 17, 5),        # A = 512: eight waves, four tiles each
+                                            (6, 77, 64, 130, 64, 17, 50),       # steps shared by three workgroups per tile
+                                            (24, 300, 640, 300, 320, 31, 60)])  # the C2 / C3 decoder shape
+def test_loc_post_mfma_matches_valu_kernel(mods, B, Tp, E, A, C, V, L):
+    """The post-loop sums d psi, d w_e, d b_e, d W_lp (att_loc_post): bf16 mode runs them on the matrix cores
+    (att_loc_post_mma), LAS_LOC_POST_VALU=1 selects the f32-mode kernel.  Same inputs, same BPTT chain before them, ragged
+    utterance AND label lengths (the MFMA kernel stops at an utterance's last step with a gradient).  d psi / d w_e are the
+    same f32 sums in another order: 1e-5 of the largest entry; d W_lp takes du and f as bf16 MFMA operands: 4e-3."""
+    import os
+    ops, dec = mods
+    rng = np.random.RandomState(B * 77 + A + L)
+    W = rand_weights(rng, V, C, E, A, 1, True)
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    nlab = rng.randint(max(1, L // 2), L + 1, size=B); nlab[0] = L
+    for b in range(B):
+        G[nlab[b]:, b] = 0.0                       # no loss, hence no gradient, behind an utterance's last label
+    names = dec.weight_names(1, True)
+    res = []
+    ops.set_precision('bf16')
+    old = os.environ.pop('LAS_LOC_POST_VALU', None)
+    try:
+        for valu in (False, True):
+            if valu:
+                os.environ['LAS_LOC_POST_VALU'] = '1'
+            Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+            enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+            psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+            status = torch.zeros(1, dtype=torch.int32, device=DEV)
+            h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                             torch.tensor(y, device=DEV), L, 1, True, None, dict(seed=0, status=status),
+                                             *[Wg[k] for k in names])
+            (h_top * torch.tensor(G, device=DEV)).sum().backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            res.append({'d psi': psi_g.grad.cpu().numpy(), 'd w_e': Wg['attention.gen_energy.weight'].grad.cpu().numpy(),
+                        'd W_lp': Wg['attention.loc_proj.weight'].grad.cpu().numpy()})
+    finally:
+        os.environ.pop('LAS_LOC_POST_VALU', None)
+        if old is not None:
+            os.environ['LAS_LOC_POST_VALU'] = old
+    for k, rel in (('d psi', 1e-5), ('d w_e', 1e-5), ('d W_lp', 4e-3)):
+        got, ref = res[0][k], res[1][k]
+        assert np.isfinite(got).all() and np.abs(ref).max() > 0
+        assert np.abs(got - ref).max() <= rel * np.abs(ref).max() + 1e-7, (k, float(np.abs(got - ref).max()), float(np.abs(ref).max()))

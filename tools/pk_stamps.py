@@ -55,9 +55,9 @@ if ws is not None:
     rows = dbg[dbg.sum(1) > 0]
     nc = int(os.environ.get('NCELL_B', 80))
     names_c = ['load saved', 'WAIT pieces+pull', 'WAIT dq_pre', 'pull dq+mma+sum', 'pw+Ksplit+publish', 'saved stores']
-    names_a = ['A3: conv + reduce', '1-u^2 (mfma+tanh)', 'WAIT pieces', 'C2: signal da', 'WAIT da', 'softmax bwd', 'E5: signal dqp/df',
+    names_a = ['A3c: load_s issue', '1-u^2 (mfma+tanh)', 'WAIT pieces', 'C2: signal da', 'WAIT da', 'softmax bwd', 'E5: signal dqp/df',
                'WAIT dq partials', 'dq_pre+publish', 'A1: s/att/f loads', 'A2: WAIT df + window load', 'B: piece sum', 'C1: da loop + stores',
-               'E1: dz,du->LDS', 'E2: dq reduce+stores', 'E3: df mfma+adds', 'E4: dfx stores']
+               'E1: dz,du->LDS', 'E2: dq reduce+stores', 'E3: df mfma+adds', 'E4: dfx stores', 'A3a: conv loop (thread 0)', 'A3b: barrier + channel sums + barrier']
     for nm, r, nms in (('cell', rows[:nc], names_c), ('att', rows[nc:], names_a)):
         print(nm, 'workgroups', len(r), 'cycles/step (sum of medians) %.0f' % sum(np.median(r[:, i]) for i in range(len(nms))))
         for i, n_ in enumerate(nms):

@@ -226,6 +226,12 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
 }
 
 // ---- attention role ----------------------------------------------------------------------------------------------
+// 16-byte vectors per channel row of the d f window (frames r0 - K .. r0 + TC + K and a margin): see pb_att_role
+__host__ __device__ inline int pb_window_vecs(int TCq) {
+    const int need = TCq + (2 * LOC_K + 12) / 4;
+    return need + ((TCq - need) % 16 + 16) % 16;
+}
+
 template <int PREC, int MT, int NTW>
 __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     typedef typename CT<PREC>::T T;
@@ -241,7 +247,10 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     const int a0 = c * g.AS, ASr = max(0, min(g.AS, A - a0));          // my d q_pre columns
     // d f window of the conv path: frames r0 - K .. r0 + TC + K; an ODD number of 16-byte vectors per channel row, so that the
     // ten channels' windows do not sit on the same LDS banks (with 256-float rows the conv's reads were 6-way conflicts)
-    const int WN = (4 * TCq + 2 * LOC_K + 12) + (((4 * TCq + 2 * LOC_K + 12) / 4) % 2 == 0 ? 4 : 0);
+    // row length in 16-byte vectors == TCq (mod 16): thread (channel cc, frame quad qd) then reads vector cc * TCq + qd (mod 16) of
+    // the 16 bank groups, i.e. the 16 lanes a b128 read serves at once hit 16 different groups (with 65 vectors per row the
+    // lanes of channel cc + 1 sat on those of channel cc: two-way conflicts on every window read)
+    const int WN = 4 * pb_window_vecs(TCq);
     // LDS (every float array 16-byte aligned)
     T* enc_l = (T*)smem;                                         // [Tp][ESp]
     float* cwf_l = (float*)(smem + (((size_t)Tp * ESp * sizeof(T) + 15) & ~(size_t)15));      // [10][LWP] FLIPPED taps, zero padded
@@ -330,7 +339,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             {
                 const float* src = a.dfx + ((size_t)((t + 1) & 1) * B + b) * LOC_C * Tp4;
                 __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, LOC_C * Tp4 * 4, 0x00020000);
-                const int wq = WN / 4;
+                const int wq = TCq + (2 * LOC_K + 12) / 4;             // (the vectors the conv reads; the row is longer, see WN)
                 for (int i = threadIdx.x; i < LOC_C * wq; i += PNT) {
                     const int cc = i / wq, x4 = i - cc * wq, tp = r0 - LOC_K + 4 * x4;
                     u32x4 v = {0u, 0u, 0u, 0u};
@@ -573,7 +582,7 @@ size_t pb_cell_lds(int prec, const PbGeom& g) {
 }
 size_t pb_att_lds(int prec, const PbGeom& g, int Tp, int A) {
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ldk = prec == LAS_PREC_BF16 ? 40 : 20;
-    const size_t Tp4 = (Tp + 3) & ~3, TCq = (g.TC + 3) / 4, WN = 4 * TCq + 2 * LOC_K + 16, lda_ = g.Ap + vec;
+    const size_t Tp4 = (Tp + 3) & ~3, TCq = (g.TC + 3) / 4, WN = 4 * (size_t)pb_window_vecs((int)TCq), lda_ = g.Ap + vec;
     const size_t scratchA = sizeof(float) * (LOC_C * WN + NSEG * LOC_C * TCq * 4), scratchE = (size_t)g.MT * 16 * lda_ * sz;
     return (size_t)Tp * (g.ES + 4) * sz + 16 +
            sizeof(float) * (LOC_C * LWP + 2 * Tp4 + g.ES + 2 * g.MT * 16 + 4 * g.NTW * PNW * 16 + g.MT * 16 * 16 + 64 + 4) +

@@ -242,7 +242,10 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E, Ap = g.Ap, NX = g.NX;
     const int len = a.lens[b];
     const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0)), tcv = max(0, min(TCr, len - r0));
-    const int ES = g.ES, e0 = c * ES, ESr = max(0, min(ES, E - e0)), ESp = ES + 4;
+    // enc rows: whole MFMA k-steps, 16-byte aligned, and a row stride (ESP + one vector) that spreads the 16 rows of an A
+    // fragment over all 64 banks (bf16: 52 dwords, f32: == 4 mod 16)
+    const int ES = g.ES, e0 = c * ES, ESr = max(0, min(ES, E - e0)), ESP = (ES + KSTEP - 1) / KSTEP * KSTEP, ESp = ESP + VEC;
+    const int Tp16 = (Tp + 15) & ~15;
     const int TCq = (TC + 3) / 4, Tp4 = (Tp + 3) & ~3, lda_ = Ap + VEC;
     const int a0 = c * g.AS, ASr = max(0, min(g.AS, A - a0));          // my d q_pre columns
     // d f window of the conv path: frames r0 - K .. r0 + TC + K; an ODD number of 16-byte vectors per channel row, so that the
@@ -252,8 +255,9 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     // lanes of channel cc + 1 sat on those of channel cc: two-way conflicts on every window read)
     const int WN = 4 * pb_window_vecs(TCq);
     // LDS (every float array 16-byte aligned)
-    T* enc_l = (T*)smem;                                         // [Tp][ESp]
-    float* cwf_l = (float*)(smem + (((size_t)Tp * ESp * sizeof(T) + 15) & ~(size_t)15));      // [10][LWP] FLIPPED taps, zero padded
+    T* enc_l = (T*)smem;                                         // [Tp16][ESp], zero beyond the utterance / my slice
+    T* dctxT_l = enc_l + (size_t)Tp16 * ESp;                     // [ESP] d ctx of my slice as an MFMA operand row
+    float* cwf_l = (float*)(smem + ((((size_t)Tp16 * ESp + ESP) * sizeof(T) + 15) & ~(size_t)15));      // [10][LWP] FLIPPED taps, zero padded
     float* att_l = cwf_l + LOC_C * LWP;                          // [Tp4]
     float* da_l = att_l + Tp4;                                   // [Tp4]
     float* dctx_l = da_l + Tp4;                                  // [ES]
@@ -276,7 +280,8 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
 
     // ---- prologue
-    for (int i = threadIdx.x; i < Tp * ESp; i += PNT) {
+    for (int i = threadIdx.x; i < ESP; i += PNT) dctxT_l[i] = (T)0;
+    for (int i = threadIdx.x; i < Tp16 * ESp; i += PNT) {
         const int tp = i / ESp, col = i - tp * ESp;
         enc_l[i] = to_ct<T>((col < ESr && tp < len) ? a.enc[((long)b * Tp + tp) * E + e0 + col] : 0.f);
     }
@@ -317,16 +322,34 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                 for (int j = 0; j < NTW; ++j) sv[mt][j][r] = sp[min((wave + PNW * j) * 16 + fr, A - 1)];
             }
     };
+    float pf_att[2] = {0.f, 0.f}, pf_f = 0.f, pf_q = 0.f;
+    const int pf_cc = (int)threadIdx.x / TC, pf_tt = (int)threadIdx.x - pf_cc * TC;
+    auto prefetch = [&](int t_) {                                // saved att (step t_ + 1's slot), f, q of step t_
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * PNT;
+            if (i < Tp) pf_att[j] = a.att[((long)(t_ + 1) * B + b) * Tp + i];
+        }
+        if ((int)threadIdx.x < LOC_C * TC)
+            pf_f = pf_tt < TCr ? a.f[(((long)t_ * B + b) * LOC_C + pf_cc) * Tp + r0 + pf_tt] : 0.f;
+        pf_q = a.q[((long)t_ * B + b) * A + min(a0 + (int)threadIdx.x, A - 1)];
+    };
+    prefetch(a.L - 1);
     PK_STAMP_DECL;
 
     for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
         // ---- (A) everything that needs no d ctx_t: attention, u = tanh(W_lp f_t), the conv path of d f_{t+1}
-        for (int i = threadIdx.x; i < Tp; i += PNT) att_l[i] = a.att[((long)(t + 1) * B + b) * Tp + i];
-        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+        // the step's saved att / f / q were requested one step ago (HBM-cold reads: waiting for them here was 3 700
+        // cycles of every step); now into LDS, and the next step's are requested
+        for (int i = threadIdx.x, j = 0; i < Tp; i += PNT, ++j)
+            att_l[i] = j < 2 ? pf_att[j] : a.att[((long)(t + 1) * B + b) * Tp + i];
+        if ((int)threadIdx.x < LOC_C * TC) Ft[pf_tt * LDK + pf_cc] = to_ct<T>(pf_f);
+        for (int i = threadIdx.x + PNT; i < LOC_C * TC; i += PNT) {          // (TC > 51: not a geometry this loop is given)
             const int cc = i / TC, tt = i - cc * TC;
             Ft[tt * LDK + cc] = to_ct<T>(tt < TCr ? a.f[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt] : 0.f);
         }
-        const float qq_f = a.q[((long)t * B + b) * A + min(a0 + (int)threadIdx.x, A - 1)];      // (for phase F)
+        const float qq_f = pf_q;                                             // (for phase F)
+        if (t > 0) prefetch(t - 1);
         PK_STAMP(9);
         if (t + 1 < a.L) {
             // d f_{t+1} of the frames around my chunk (published by my utterance's parts at the end of step t+1)
@@ -437,21 +460,23 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             }
             part4 += las_dpp<0x111, 0xf>(0.f, part4);
             part4 += las_dpp<0x112, 0xf>(0.f, part4);
-            if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) dctx_l[threadIdx.x >> 2] = part4;
+            if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) { dctx_l[threadIdx.x >> 2] = part4; dctxT_l[threadIdx.x >> 2] = to_ct<T>(part4); }
         }
         __syncthreads();
         PK_STAMP(11);
         // ---- (C) d a over my E-slice for every frame of the utterance (+ the conv path for my own frames)
-        for (int tp = threadIdx.x; tp < len; tp += PNT) {
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-            const T* er_ = enc_l + (size_t)tp * ESp;
-            for (int e = 0; e < ES; e += 4) {
-                const float4 v = ld4(er_ + e), d = *(const float4*)(dctx_l + e);
-                c0 = fmaf(v.x, d.x, c0); c1 = fmaf(v.y, d.y, c1); c2 = fmaf(v.z, d.z, c2); c3 = fmaf(v.w, d.w, c3);
+        // on the matrix cores: A = 16 frames x my slice of enc (LDS), B = the d ctx row for all 16 columns (ldb = 0: every lane of
+        // a row group ends with the same four frames' sums); a wave per 16-frame tile.  (A thread per frame walking its row with
+        // scalar FMAs was 3 900 cycles of every step, on the chain between the cells' pieces and the softmax backward.)
+        for (int tile = wave; tile * 16 < len; tile += PNW) {
+            f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+            mma_rows<PREC, 1>(acc, enc_l + (size_t)tile * 16 * ESp, ESp, dctxT_l, 0, ESP / KSTEP);
+            const int tp = tile * 16 + fq * 4 + fr;                          // lane fr < 4 of a row group stores row fr
+            float v = fr == 0 ? acc[0][0] : fr == 1 ? acc[0][1] : fr == 2 ? acc[0][2] : acc[0][3];
+            if (fr < 4 && tp < len) {
+                if (tp >= r0 && tp < r0 + TCr) v += ct_l[tp - r0];
+                st_sc1(a.dax + (((size_t)(t & 1) * B + b) * g.NCH + c) * Tp + tp, v);
             }
-            float v = (c0 + c1) + (c2 + c3);
-            if (tp >= r0 && tp < r0 + TCr) v += ct_l[tp - r0];
-            st_sc1(a.dax + (((size_t)(t & 1) * B + b) * g.NCH + c) * Tp + tp, v);
         }
         PK_STAMP(12);
         pk_signal(&a.sync->cnt_da[b][0]);
@@ -584,7 +609,8 @@ size_t pb_att_lds(int prec, const PbGeom& g, int Tp, int A) {
     const int sz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4, ldk = prec == LAS_PREC_BF16 ? 40 : 20;
     const size_t Tp4 = (Tp + 3) & ~3, TCq = (g.TC + 3) / 4, WN = 4 * (size_t)pb_window_vecs((int)TCq), lda_ = g.Ap + vec;
     const size_t scratchA = sizeof(float) * (LOC_C * WN + NSEG * LOC_C * TCq * 4), scratchE = (size_t)g.MT * 16 * lda_ * sz;
-    return (size_t)Tp * (g.ES + 4) * sz + 16 +
+    const size_t ks = prec == LAS_PREC_BF16 ? 32 : 16, ESP = (g.ES + ks - 1) / ks * ks, Tp16 = ((size_t)Tp + 15) & ~(size_t)15;
+    return (Tp16 * (ESP + vec) + ESP) * sz + 16 +
            sizeof(float) * (LOC_C * LWP + 2 * Tp4 + g.ES + 2 * g.MT * 16 + 4 * g.NTW * PNW * 16 + g.MT * 16 * 16 + 64 + 4) +
            ((size_t)g.NTW * PNW * 16 * ldk + 16 * lda_ + (size_t)g.MT * 16 * ldk) * sz + 16 + (scratchA > scratchE ? scratchA : scratchE) + 64;
 }

@@ -83,7 +83,8 @@ def kernel_timing_summary(records):
 # Weight-gradient GEMMs are off the backward dependency chain, and the persistent LSTM kernels that follow them
 # occupy only ND*ceil(H/16)*slices CUs: run the wgrads on a second HIP stream, accumulating directly into the
 # flat gradient buffer (param.grad views), and join before the optimiser.
-_SIDE = {'enabled': True, 'stream': None, 'stream1': None, 'dirty': False, 'dirty1': False}
+_SIDE = {'enabled': True, 'stream': None, 'stream1': None, 'dirty': False, 'dirty1': False,
+         'inline': bool(os.environ.get('LAS_WGRAD_INLINE'))}
 _BRANCH = {'stream': None, 'enabled': not os.environ.get('LAS_NO_CTC_BRANCH')}
 _GRAD_READY = None      # dist.backward_with_overlap: called with an encoder layer's first gradient view once that layer's
                         # (and therefore every later parameter's) gradients have all been enqueued
@@ -91,6 +92,13 @@ _GRAD_READY = None      # dist.backward_with_overlap: called with an encoder lay
 
 def set_wgrad_overlap(flag):
     _SIDE['enabled'] = bool(flag)
+
+
+def set_wgrad_inline(flag):
+    """True: the weight-gradient work that normally goes to the side streams runs on the current stream instead (same
+    kernels, same accumulation into the flat gradient buffer).  For shapes whose persistent LSTM kernels fill every CU
+    (H = 1024: 256 workgroups) there is nothing for a side stream to overlap with, only contention."""
+    _SIDE['inline'] = bool(flag)
 
 
 _ONE_SIDE = bool(os.environ.get('LAS_ONE_SIDE_STREAM'))      # (A/B measurements: all weight-gradient work on one side stream)
@@ -156,6 +164,13 @@ def on_side_stream(fn, inputs, which=0, after=None):
     event `after`, if given); `inputs` are tensors fn reads (kept alive for the side stream through record_stream).
     Returns an event recorded on the side stream behind fn()."""
     main = torch.cuda.current_stream()
+    if _SIDE['inline']:                     # (set_wgrad_inline: the same work in the same order on the current stream)
+        if after is not None:
+            main.wait_event(after)
+        fn()
+        done = torch.cuda.Event()
+        done.record(main)
+        return done
     side = _side_stream(which)
     ev = torch.cuda.Event()
     ev.record(main)
@@ -557,13 +572,12 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
         gw_ih, gw_hh, gb_ih, gb_hh = targets
         dgf16 = twin(dgf, make=True) if need_gx else None
         gx = gemm(dgf, w_ih, A16=dgf16, B16=w_ih16).view(T, B, Iin) if need_gx else None
-        s0, s1 = _side_stream(0), _side_stream(1)
         box = {}
 
         def part1():
             box['hf16'] = twin(hf2, make=True)
             box['e_hf'] = torch.cuda.Event()
-            box['e_hf'].record(s1)
+            box['e_hf'].record(torch.cuda.current_stream())
             colsum(dgf, gb_ih, beta=1.0, out2=gb_hh)
 
         def part0a():
@@ -577,7 +591,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
             w_hh_grad(0, gw_hh, 1.0, box['d16'], box['hf16'])
 
         def part1b():
-            s1.wait_event(box['e_d16'])
+            torch.cuda.current_stream().wait_event(box['e_d16'])
             for d in range(1, ND):
                 w_hh_grad(d, gw_hh, 1.0, box['d16'], box['hf16'])
 

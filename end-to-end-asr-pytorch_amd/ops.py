@@ -42,7 +42,8 @@ class _Timed:
     def __exit__(self, *exc):
         if _TIMING is not None:
             self.e1.record()
-            _TIMING.append((self.args[0], self.e0, self.e1, self.args[1], self.args[2], self.args[3], self.args[4]))
+            beside = _BRANCH['stream'] is not None and torch.cuda.current_stream() == _BRANCH['stream']
+            _TIMING.append((self.args[0], self.e0, self.e1, self.args[1], self.args[2], self.args[3], self.args[4], beside))
         return False
 
 
@@ -51,8 +52,8 @@ def kernel_timing_summary(records):
     groups that are one kernel launch per call, named as rocprofv3 names it); every group is in `breakdown`."""
     torch.cuda.synchronize()
     groups = {}
-    for name, e0, e1, work, unit, single, dep in records:
-        g = groups.setdefault(name, dict(ms=0.0, n=0, work=0.0, unit=unit, single=single, dep=0))
+    for name, e0, e1, work, unit, single, dep, beside in records:
+        g = groups.setdefault(name, dict(ms=0.0, n=0, work=0.0, unit=unit, single=single, dep=0, beside=beside))
         g['ms'] += e0.elapsed_time(e1)
         g['n'] += 1
         g['work'] += work
@@ -69,6 +70,8 @@ def kernel_timing_summary(records):
             row = dict(kernel=name, bound='hbm', achieved=ach, peak=PEAK['hbm'], unit='GB/s', frac=ach / PEAK['hbm'])
         row.update(launches=g['n'], avg_launch_ms=g['ms'] / g['n'], total_ms=g['ms'], single_kernel=bool(g['single']),
                    algorithmic_work_per_launch=g['work'] / g['n'], traffic=None)
+        if g['beside']:             # bracket on the CTC branch stream: its kernels share the GPU with the persistent decoder loop
+            row['beside_main_stream'] = True        # (wall time of the bracket, mostly spent waiting for CUs; not on the step's path)
         if g['dep']:
             row['us_per_dependent_step'] = g['ms'] * 1e3 / g['dep']
         rows.append(row)

@@ -2,7 +2,7 @@
 # round-2 measurement set, part 1 (one gpurun call): GPU tests, PMC passes (-> profiles/r02_pmc_traffic_c3.json on the box, so that
 # the bench line that follows carries this build's traffic), bench c3 (+cpu baseline), rocprof stats
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 700 python -m pytest tests -q -x -m gpu > gpurun_out/final_tests.log 2>&1 || { tail -30 gpurun_out/final_tests.log; exit 1; }
+timeout -k 10 800 python -m pytest tests -q -x -m gpu > gpurun_out/final_tests.log 2>&1 || { tail -30 gpurun_out/final_tests.log; exit 1; }
 tail -1 gpurun_out/final_tests.log
 rm -rf gpurun_out/final_pmc_FETCH_SIZE gpurun_out/final_pmc_WRITE_SIZE gpurun_out/final_prof_c3
 for c in FETCH_SIZE WRITE_SIZE; do

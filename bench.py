@@ -110,8 +110,19 @@ def attach_pmc_traffic(roof, workload):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from pmc_summary import kernel_sources_sha
     stale = meta.get('kernel_sources_sha') != kernel_sources_sha()     # counters were taken on other kernel sources
+    # multi-kernel brackets whose HBM traffic is that of ONE launch each of the named kernels (the persistent loops and the
+    # post-loop sums of the same C-ABI call; the zero fills and the per-step fallback kernels are not counted)
+    group_kernels = {'decoder_bwd (L steps BPTT)': ('dec_pk_bwd_kernel', 'att_loc_post_mma', 'att_loc_post'),
+                     'decoder_fwd (L attend+spell steps)': ('dec_pk_fwd_kernel',)}
     for row in [roof] + roof.get('breakdown', []):
         if not row.get('single_kernel'):
+            names = group_kernels.get(row['kernel'])
+            per = [[v for n, v in pmc.items() if n.split('<')[0] == k] for k in (names or ())]
+            if names and per[0]:
+                row['traffic'] = sum(sum(h['hbm_MB_per_launch_corrected'] * h['launches'] for h in hs) / sum(h['launches'] for h in hs)
+                                     for hs in per if hs) * 1e6
+                row['traffic_unit'] = 'B/call: one launch each of ' + ' + '.join(k for k, hs in zip(names, per) if hs) + ' (PMC, ' + os.path.basename(path) + ')'
+                row['traffic_stale'] = stale
             continue
         hits = [v for n, v in pmc.items() if n.split('<')[0] == row['kernel']]
         if hits:

@@ -44,6 +44,7 @@ struct PbSync {                         // zeroed before every launch
 struct PbGeom {
     int U, NCT, NS, Bs, NB, NCELL;
     int NCH, TC, ES, MT, NTW;
+    int xl;                             // attention parts of an utterance on block ids that are congruent mod 8 (one XCD, observed)
     int NX;                             // piece row: [0,E) d ctx, [E,E+C) d h; padded to 16
     int Ap;                             // A padded to the MFMA k-step
     int AS;                             // d q_pre columns reduced per attention part
@@ -81,6 +82,46 @@ __device__ __forceinline__ void st4_sc1(float* p, float a, float b, float c, flo
 }
 __device__ __forceinline__ float ldb_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 16));
+}
+// ---- exchanges among the parts of ONE utterance (d a, d q partials, d f): when all its parts sit on one XCD (checked at
+// run time, pb_utt_local) they use the LSTM's L2-local form (lstm.hip): the payload as PLAIN stores (write-through L1, the
+// line stays in the XCD's L2, where the readers' L1-bypassing loads find it), the signal as a plain store of the step
+// count to the part's own progress word (no atomic: an agent-scope atomic and its poll go to the memory side), the wait a
+// poll of the NCH words.  Otherwise: sc1 stores and one atomic counter, as between the roles.
+__device__ __forceinline__ void st_x(float* p, float v, bool local) {
+    if (local) *p = v;
+    else st_sc1(p, v);
+}
+__device__ __forceinline__ void pk_signal_x(unsigned* line, int part, unsigned steps, bool local) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == PNT - 64) {
+        if (local) line[1 + part] = steps;
+        else __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool pk_block_wait_x(unsigned* line, int nparts, unsigned steps, bool local, unsigned* abort_word, int* flag) {
+    return local ? pk_block_wait(line + 1, 1, nparts, steps, abort_word, flag)
+                 : pk_block_wait(line, 0, 1, (unsigned)nparts * steps, abort_word, flag);
+}
+// 1: every part of the utterance reported the same hardware XCC id; 0: not (or the id mapping is not the XCD-grouped one);
+// -1: timeout.  One rendezvous before the first step through agent-scope atomics on words 32..34 of the utterance's d a line.
+__device__ __forceinline__ int pb_utt_local(unsigned* line, int nparts, bool try_local, unsigned* abort_word, int* flag) {
+    if (!try_local) return 0;
+    unsigned* w = line + 32;
+    if (threadIdx.x == PNT - 64) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 15u;
+        const unsigned o1 = __hip_atomic_fetch_max(w + 1, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned o2 = __hip_atomic_fetch_max(w + 2, 16u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o1), "v"(o2) : "memory");          // both maxima performed before the arrival below
+        __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!pk_block_wait(w, 0, 1, (unsigned)nparts, abort_word, flag)) return -1;
+    const unsigned mx = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   mn = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mx + mn == 17u ? 1 : 0;
 }
 __device__ __forceinline__ float ct2f(float v) { return v; }
 __device__ __forceinline__ float ct2f(bf16_t v) { return bf2f(v); }
@@ -237,7 +278,15 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     typedef typename CT<PREC>::T T;
     constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
     const PbGeom& g = a.g;
-    const int id = blockIdx.x - g.NCELL, b = id / g.NCH, c = id - b * g.NCH;
+    // block -> (utterance b, part c).  XCD-grouped: block ids congruent mod 8 share an XCD (observed, not contractual; NCELL is a
+    // multiple of 8 then), so utterance b = 8 slot + x takes the ids == x (mod 8); ids without an utterance exit at once
+    int b, c;
+    {
+        const int id = blockIdx.x - g.NCELL;
+        if (g.xl) { const int m = id >> 3; b = (m / g.NCH) * 8 + (id & 7); c = m % g.NCH; }
+        else { b = id / g.NCH; c = id - b * g.NCH; }
+    }
+    if (b >= a.B) return;
     const int bs = b / g.Bs;
     const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E, Ap = g.Ap, NX = g.NX;
     const int len = a.lens[b];
@@ -305,6 +354,12 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? a.w_e[aa] : 0.f; }
     unsigned* abort_word = a.sync->abort_;
     unsigned nwait = 0;
+    const int loc_ = pb_utt_local(&a.sync->cnt_da[b][0], g.NCH, g.xl != 0, abort_word, flag + 2);
+    if (loc_ < 0) {
+        if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+        return;
+    }
+    const bool local = loc_ > 0;            // my utterance's parts share an XCD: L2-local exchanges among them
     T* px = (T*)a.px;
     T* dqq = (T*)a.dqq;
     const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
@@ -353,7 +408,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         PK_STAMP(9);
         if (t + 1 < a.L) {
             // d f_{t+1} of the frames around my chunk (published by my utterance's parts at the end of step t+1)
-            if (!pk_block_wait(&a.sync->cnt_df[b][0], 0, 1, (unsigned)g.NCH * (n - 1), abort_word, flag + (nwait++ & 1))) {
+            if (!pk_block_wait_x(&a.sync->cnt_df[b][0], g.NCH, (unsigned)(n - 1), local, abort_word, flag + (nwait++ & 1))) {
                 if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
                 return;
             }
@@ -475,15 +530,15 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             float v = fr == 0 ? acc[0][0] : fr == 1 ? acc[0][1] : fr == 2 ? acc[0][2] : acc[0][3];
             if (fr < 4 && tp < len) {
                 if (tp >= r0 && tp < r0 + TCr) v += ct_l[tp - r0];
-                st_sc1(a.dax + (((size_t)(t & 1) * B + b) * g.NCH + c) * Tp + tp, v);
+                st_x(a.dax + (((size_t)(t & 1) * B + b) * g.NCH + c) * Tp + tp, v, local);
             }
         }
         PK_STAMP(12);
-        pk_signal(&a.sync->cnt_da[b][0]);
+        pk_signal_x(&a.sync->cnt_da[b][0], c, (unsigned)n, local);
         PK_STAMP(3);
         if (threadIdx.x < ESr) a.dxin[((long)t * B + b) * XI + C + e0 + threadIdx.x] = dctx_l[threadIdx.x];
         // ---- (D) all parts' d a: softmax backward for my frames
-        if (!pk_block_wait(&a.sync->cnt_da[b][0], 0, 1, (unsigned)g.NCH * n, abort_word, flag + (nwait++ & 1))) {
+        if (!pk_block_wait_x(&a.sync->cnt_da[b][0], g.NCH, (unsigned)n, local, abort_word, flag + (nwait++ & 1))) {
             if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
             return;
         }
@@ -536,7 +591,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         __syncthreads();
         for (int aa = threadIdx.x; aa < A; aa += PNT) {
             const float v = (dqp_l[aa] + dqp_l[NTW * PNW * 16 + aa]) + (dqp_l[2 * NTW * PNW * 16 + aa] + dqp_l[3 * NTW * PNW * 16 + aa]);
-            st_sc1(a.dqx + (((size_t)(t & 1) * B + b) * g.NCH + c) * Ap + aa, v);
+            st_x(a.dqx + (((size_t)(t & 1) * B + b) * g.NCH + c) * Ap + aa, v, local);
         }
         PK_STAMP(14);
         // d f[c][t'] = sum_a d u[t'][a] W_lp[a][c]: MFMA over k = a, the waves split the k-steps, LDS float adds combine them
@@ -552,18 +607,21 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         PK_STAMP(15);
         for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
-            if (tt < TCr) st_sc1(a.dfx + (((size_t)(t & 1) * B + b) * LOC_C + cc) * Tp4 + r0 + tt, tt < tcv ? dfa_l[tt * 16 + cc] : 0.f);
+            if (tt < TCr) st_x(a.dfx + (((size_t)(t & 1) * B + b) * LOC_C + cc) * Tp4 + r0 + tt, tt < tcv ? dfa_l[tt * 16 + cc] : 0.f, local);
         }
         PK_STAMP(16);
-        pk_signal(&a.sync->cnt_dqp[b][0]);
-        if (threadIdx.x == PNT - 64) __hip_atomic_fetch_add(&a.sync->cnt_df[b][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pk_signal_x(&a.sync->cnt_dqp[b][0], c, (unsigned)n, local);
+        if (threadIdx.x == PNT - 64) {                      // (the same drain + barrier covers the d f stores)
+            if (local) a.sync->cnt_df[b][1 + c] = (unsigned)n;
+            else __hip_atomic_fetch_add(&a.sync->cnt_df[b][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         PK_STAMP(6);
         for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
             if (tt < tcv) __builtin_nontemporal_store(dfa_l[tt * 16 + cc], &a.df[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt]);
         }
         // ---- (F) d q_pre of my a-slice: sum of the parts' partials, times (1 - q^2); to the cell role
-        if (!pk_block_wait(&a.sync->cnt_dqp[b][0], 0, 1, (unsigned)g.NCH * n, abort_word, flag + (nwait++ & 1))) {
+        if (!pk_block_wait_x(&a.sync->cnt_dqp[b][0], g.NCH, (unsigned)n, local, abort_word, flag + (nwait++ & 1))) {
             if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
             return;
         }
@@ -653,6 +711,9 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
         g.AS = ((d->A + g.NCH - 1) / g.NCH + 1) / 2 * 2;
         if (g.AS > PNT) continue;
         if (pb_att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
+        // XCD-grouped attention blocks: utterance b on the ids == b (mod 8) behind the cells (NCELL a multiple of 8), if the
+        // padded grid still is one workgroup per CU
+        g.xl = (!getenv("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= 256) ? 1 : 0;
         g.lds = pb_cell_lds(d->prec, g);
         const size_t al = pb_att_lds(d->prec, g, d->Tp, d->A);
         if (al > g.lds) g.lds = al;
@@ -704,7 +765,7 @@ int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     a.dgates = bw->dgates; a.dxin = bw->dxin; a.dq_pre = bw->dq_pre; a.de = bw->de; a.df = bw->df;
     a.px = ws + w.px; a.dax = (float*)(ws + w.dax); a.dqx = (float*)(ws + w.dqx); a.dfx = (float*)(ws + w.dfx); a.dqq = ws + w.dqq;
     a.sync = (PbSync*)(ws + w.sync); a.status = bw->pk_status; a.dbg = (unsigned long long*)(ws + w.dbg);
-    const int grid = g.NCELL + B * g.NCH;
+    const int grid = g.NCELL + (g.xl ? 8 * ((B + 7) / 8) * g.NCH : B * g.NCH);
     int launched = 0;
 #define LAS_PB_GO(P_, N_, M_, W_)                                                                                  \
     {                                                                                                             \

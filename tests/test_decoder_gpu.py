@@ -358,3 +358,52 @@ def test_loc_post_mfma_matches_valu_kernel(mods, B, Tp, E, A, C, V, L):
         got, ref = res[0][k], res[1][k]
         assert np.isfinite(got).all() and np.abs(ref).max() > 0
         assert np.abs(got - ref).max() <= rel * np.abs(ref).max() + 1e-7, (k, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('B,Tp,E,A,C,V,L', [(24, 300, 640, 300, 320, 31, 6), (16, 77, 96, 130, 64, 17, 5)])
+def test_persistent_bptt_exchange_forms_agree(mods, B, Tp, E, A, C, V, L):
+    """The BPTT loop's exchanges among an utterance's parts: L2-local form (XCD-grouped block ids, plain stores + progress
+    words, taken when the run-time XCC-id check passes) against the sc1 + counter form (LAS_DEC_NO_XL=1).  Same arithmetic in
+    the same order: every gradient equal to 1e-6 of its largest entry."""
+    import os
+    ops, dec = mods
+    rng = np.random.RandomState(B * 31 + Tp + L)
+    W = rand_weights(rng, V, C, E, A, 1, True)
+    lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    names = dec.weight_names(1, True)
+    res = []
+    ops.set_precision('bf16')
+    old = os.environ.pop('LAS_DEC_NO_XL', None)
+    try:
+        for no_xl in (False, True):
+            if no_xl:
+                os.environ['LAS_DEC_NO_XL'] = '1'
+            Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+            enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+            psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+            status = torch.zeros(1, dtype=torch.int32, device=DEV)
+            h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                             torch.tensor(y, device=DEV), L, 1, True, None, dict(seed=0, status=status),
+                                             *[Wg[k] for k in names])
+            (h_top * torch.tensor(G, device=DEV)).sum().backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            res.append(dict({'d enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
+                            **{k: Wg[k].grad.cpu().numpy() for k in names if not k.startswith('char_trans')}))
+    finally:
+        os.environ.pop('LAS_DEC_NO_XL', None)
+        if old is not None:
+            os.environ['LAS_DEC_NO_XL'] = old
+    for k in res[0]:
+        a0, a1 = res[0][k], res[1][k]
+        assert np.isfinite(a0).all()
+        if k == 'attention.gen_energy.bias':
+            continue                     # (a sum that cancels to rounding noise; float atomics in another order)
+        assert np.abs(a0 - a1).max() <= 1e-6 * np.abs(a1).max() + 1e-9, (k, float(np.abs(a0 - a1).max()), float(np.abs(a1).max()))

@@ -66,7 +66,7 @@ struct PbArgs {
     float* dax;                         // [2][B][NCH][Tp]
     float* dqx;                         // [2][B][NCH][Ap]
     float* dfx;                         // [2][B][10][Tp]
-    void* dqq;                          // [2][B][Ap] compute type: d q_pre
+    void* dqq;                          // [2][B][Ap / V8] 16-byte granules {V8 values of d q_pre (4 bf16 | 2 f32), 0, tag = step count}
     PbSync* sync; int* status;
     unsigned long long* dbg;
 };
@@ -169,7 +169,6 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
     unsigned* abort_word = a.sync->abort_;
     unsigned nwait = 0;
     T* px = (T*)a.px;
-    T* dqq = (T*)a.dqq;
     PK_STAMP_DECL;
 
     for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
@@ -201,12 +200,33 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
                 }
             }
             PK_STAMP(1);
-            if (!pk_block_wait(&a.sync->cnt_dq[b0][0], CLW, Bl, (unsigned)g.NCH * (n - 1), abort_word, flag + (nwait++ & 1))) {
-                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-                return;
+            // d q_pre of step t+1 arrives as tagged granules (pk_common.h): no counter, no poll-then-pull -- the sweep IS the
+            // pull, one L2 round trip once the last part has stored (this hand-off is on the loop's chain; as flag + data it
+            // cost a drain, a barrier, an atomic, a poll round trip, a barrier and the pull's round trip)
+            {
+                constexpr int V8 = GrT<T>::V8;
+                const int NGr = Ap / V8, NGu = min(NGr, g.NCH * g.AS / V8), total = Bl * NGu;
+                __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dqq + ((size_t)((t + 1) & 1) * B + b0) * NGr * 16), 0,
+                                                                             Bl * NGr * 16, 0x00020000);
+                auto sweep = [&](auto swv) -> bool {
+                    constexpr int SW = decltype(swv)::value;
+                    int off[SW], dst[SW];
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) {
+                        const int i = threadIdx.x + u * PNT, r = i / NGu, gc = i - r * NGu;
+                        off[u] = i < total ? (r * NGr + gc) * 16 : GR_OOB;
+                        dst[u] = r * ldq + gc * V8;
+                    }
+                    return pk_gr_sweep<SW>(rq, off, (unsigned)(n - 1), abort_word, [&](int u, const u32x4& gv) { pk_gr_scatter<T, 2>(Ql + dst[u], gv); });
+                };
+                const bool ok = total <= 2 * PNT ? sweep(std::integral_constant<int, 2>{}) : total <= 4 * PNT ? sweep(std::integral_constant<int, 4>{})
+                                                                                                             : sweep(std::integral_constant<int, 8>{});
+                if (!ok) {
+                    if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                    return;
+                }
             }
             PK_STAMP(2);
-            pk_pull<T, VEC, 2>(dqq + ((size_t)((t + 1) & 1) * B + b0) * Ap, Bl, Ap, Ap, Ql, ldq);
             __syncthreads();
             f32x4 qa[NB];
 #pragma unroll
@@ -361,7 +381,6 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     }
     const bool local = loc_ > 0;            // my utterance's parts share an XCD: L2-local exchanges among them
     T* px = (T*)a.px;
-    T* dqq = (T*)a.dqq;
     const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
               cv_qd = threadIdx.x - cv_sg * (LOC_C * TCq) - cv_cc * TCq;
     // window origin: dfn_l[cc][x] = d f_next[cc][r0 - LOC_K - sh + x], sh chosen so that frame r0's window start is 16-byte aligned
@@ -640,9 +659,16 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                 for (int pc = 0; pc < 16; ++pc) v += pv_[pc];
                 v *= 1.f - qq * qq;
             }
-            const float vnext = las_dpp<0x101, 0xf>(0.f, v);
-            if (k < ASr && !(k & 1)) st_pair_sc1(dqq + ((size_t)(t & 1) * B + b) * Ap + aa, v, k + 1 < ASr ? vnext : 0.f);
-            pk_signal(&a.sync->cnt_dq[b][0]);
+            // to the cells as tagged granules: lane k (a multiple of V8) gathers the V8 values that start at it over DPP and
+            // stores {payload, tag = step count} with ONE 16-byte sc1 store; every one of my AS columns goes out (zeros beyond A)
+            {
+                constexpr int V8 = GrT<T>::V8;
+                const int NGr = Ap / V8;
+                unsigned w2[3];
+                pk_gr_gather8<T>(k < ASr ? v : 0.f, w2);
+                __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dqq + ((size_t)(t & 1) * B + b) * NGr * 16), 0, NGr * 16, 0x00020000);
+                pk_gr_store(rq, (k < g.AS && k % V8 == 0 && (a0 + k) / V8 < NGr) ? ((a0 + k) / V8) * 16 : GR_OOB, w2[0], w2[1], 0u, (unsigned)n);
+            }
             if (k < ASr) a.dq_pre[((long)t * B + b) * A + aa] = v;
         }
         PK_STAMP(8);
@@ -708,7 +734,7 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
         if (g.NTW == 4 && g.MT == 4) continue;
         g.ES = ((d->E + g.NCH - 1) / g.NCH + vec - 1) / vec * vec;
         if (g.ES / 4 > PNT || g.ES > PNT) continue;
-        g.AS = ((d->A + g.NCH - 1) / g.NCH + 1) / 2 * 2;
+        { const int v8 = d->prec == LAS_PREC_BF16 ? 4 : 2; g.AS = ((d->A + g.NCH - 1) / g.NCH + v8 - 1) / v8 * v8; }      // whole d q_pre granules per part
         if (g.AS > PNT) continue;
         if (pb_att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
         // XCD-grouped attention blocks: utterance b on the ids == b (mod 8) behind the cells (NCELL a multiple of 8), if the
@@ -735,7 +761,7 @@ PbWs pb_ws(const las_dec_dims* d, const PbGeom& g) {
     w.dax = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * d->Tp);
     w.dqx = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * g.Ap);
     w.dfx = o; o += las_align(sizeof(float) * 2 * d->B * LOC_C * ((d->Tp + 3) & ~3));
-    w.dqq = o; o += las_align((size_t)2 * d->B * g.Ap * sz);
+    w.dqq = o; o += las_align((size_t)2 * d->B * (g.Ap / (d->prec == LAS_PREC_BF16 ? 4 : 2)) * 16);       // granules of 4 bf16 | 2 f32
     w.total = o;
     return w;
 }

@@ -859,6 +859,10 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
         LAS_LAUNCH_OK();
     }
     // embedding rows
+    if (pk) {
+        int rc = las_dec_pk_bwd_emb(d, p, bw_, st);
+        if (rc) return rc;
+    }
     LAS_HIP(hipMemsetAsync(w.demb, 0, sizeof(float) * (size_t)d->V * C, st));
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(L * B), dim3(256), 0, st, s.tok, w.dxin, XI, C, w.demb);
     LAS_LAUNCH_OK();

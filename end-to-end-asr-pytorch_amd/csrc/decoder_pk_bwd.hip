@@ -781,7 +781,7 @@ int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     LAS_CHECK_ARG(bw->pk_ws && bw->pk_status && st->f && st->s && bw->df && bw->de && p->conv_w && p->w_lp && p->w_e);
     const PbWs w = pb_ws(d, g);
     char* ws = (char*)bw->pk_ws;
-    const int B = d->B, C = d->C, E = d->E, XI = C + E, L = d->L;
+    const int B = d->B, C = d->C, E = d->E, L = d->L;
     LAS_HIP(hipMemsetAsync(ws, 0, w.total, stream));
     PbArgs a{};
     a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g;
@@ -814,8 +814,13 @@ int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* 
 #undef LAS_PB_M
 #undef LAS_PB_W
 #undef LAS_PB_GO
-    if (!launched) return LAS_E_BADARG;
-    // d xin's embedding half for every step: d gates [L*B x 4C] x W_ih[:, 0:C]   (off the sequential chain: one GEMM)
+    return launched ? LAS_OK : LAS_E_BADARG;
+}
+
+// d xin's embedding half for every step: d gates [L*B x 4C] x W_ih[:, 0:C] -- one GEMM, read by the embedding-row sums only
+// (a parameter gradient: las_decoder_bwd_parts runs it with them, off the caller's main stream)
+int las_dec_pk_bwd_emb(const las_dec_dims* d, const las_dec_params* p, las_dec_bwd_state* bw, hipStream_t stream) {
+    const int B = d->B, C = d->C, XI = C + d->E, L = d->L;
     return las_gemm(d->prec, 0, 0, L * B, C, 4 * C, 1.f, bw->dgates, 4 * C, 0, p->w_ih[0], XI, 0, 0.f, bw->dxin, XI, 0, nullptr, 0, 1,
                     (void*)stream);
 }

@@ -110,3 +110,83 @@ def test_exec_runs_and_logs(tmp_path):
     assert len(full) == 13 and all(np.isfinite(full))          # total_steps + 1 steps, as the reference
     assert min(full[-3:]) < full[0]
     assert os.path.exists(os.path.join(tmp, 'ckpt', 'ex', 'asr'))
+
+
+def test_train_step_stream_forms_agree(tmp_path):
+    """One train step on the same batch and the same initial weights, in every scheduling form of the step:
+      * default (everything ordered behind the current stream),
+      * inputs_ready=True (length inference + its D2H on their own stream; the host runs ahead),
+      * inputs_ready=<event> (batch copied on the copy stream, as Trainer.exec does),
+      * weight gradients on the main stream (ops.set_wgrad_inline) and the CTC branch switched off.
+    Streams change WHEN kernels run, never what they compute: losses equal, gradients equal up to the order of the float
+    atomics of the split-K / column-sum kernels (1e-5 of the largest entry)."""
+    importlib.import_module('end-to-end-asr-pytorch_amd')
+    solver = importlib.import_module('end-to-end-asr-pytorch_amd.solver')
+    ops = importlib.import_module('end-to-end-asr-pytorch_amd.ops')
+    synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
+    tmp = str(tmp_path)
+    cfg = dict(asr_model=dict(optimizer=dict(type='Adadelta', learning_rate=1.0, joint_ctc=0.5),
+                              encoder=dict(enc_type='BiRNN', sample_rate='2_2_1', sample_style='concat', dim='48_48_48',
+                                           dropout='0_0_0', rnn_cell='LSTM'),
+                              attention=dict(att_mode='loc', dim=40, proj=True, num_head=1),
+                              decoder=dict(dim=48, layer=1, dropout=0, rnn_cell='LSTMCell')),
+               clm=dict(enable=False),
+               solver=dict(dataset='synthetic', data_path='', n_jobs=0, max_timestep=0, max_label_len=0, train_set=['train'],
+                           batch_size=8, apex=False, total_steps=4, tf_start=1.0, tf_end=1.0, dev_set=['dev'],
+                           dev_batch_size=4, dev_step=100, test_set=['test'], decode_beam_size=1,
+                           synthetic=dict(T_max=96, D=20, V=17, L_max=9, time_reduction=4, n_batches=2)))
+    paras = argparse.Namespace(gpu=True, name='sf', config='config/sf.yaml', seed=0, ckpdir=os.path.join(tmp, 'ckpt'),
+                               logdir=os.path.join(tmp, 'log'), load=None, verbose=False, njobs=1)
+    torch.manual_seed(0)
+    ops.set_precision('f32')
+    try:
+        t = solver.Trainer(cfg, paras)
+        t.load_data()
+        t.set_model()
+        x, y, lens = synth.make_batch(3, 8, 96, 20, 17, 9, 4, ctc=True)
+        w0 = t.asr_model.flat_params.clone()
+
+        def one(form):
+            with torch.no_grad():
+                t.asr_model.flat_params.copy_(w0)
+            t.asr_model.sync_bf16()
+            t.asr_opt.zero_grad()
+            grads = {}
+            step_ = t.asr_opt.step
+
+            def look(zero_grad=True):                           # look at the summed gradient, do not update
+                ops.join_side_stream()
+                grads['g'] = t.asr_model.flat_grads.clone()
+            t.asr_opt.step = look
+            try:
+                if form == 'event':
+                    with torch.cuda.stream(ops.copy_stream()):
+                        xd, yd = x.pin_memory().to(t.device, non_blocking=True), y.pin_memory().to(t.device, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(ops.copy_stream())
+                    for v in (xd, yd):
+                        v.record_stream(torch.cuda.current_stream())
+                    out = t.train_step(xd, yd, 1.0, inputs_ready=ev)
+                else:
+                    xd, yd = x.to(t.device), y.to(t.device)
+                    if form == 'inline':
+                        ops.set_wgrad_inline(True)
+                        ops._BRANCH['enabled'] = False
+                    out = t.train_step(xd, yd, 1.0, inputs_ready=True if form == 'ready' else None)
+                ops.join_side_stream()
+                torch.cuda.synchronize()
+            finally:
+                t.asr_opt.step = step_
+                ops.set_wgrad_inline(False)
+                ops._BRANCH['enabled'] = True
+            assert int(t.asr_model.status.item()) == 0
+            return [float(v) for v in out[:3]], grads['g'].cpu().numpy()
+
+        ref_l, ref_g = one('default')
+        assert np.isfinite(ref_l).all() and np.abs(ref_g).max() > 0
+        for form in ('ready', 'event', 'inline'):
+            l, g = one(form)
+            np.testing.assert_allclose(l, ref_l, rtol=1e-6, err_msg=form)
+            assert np.abs(g - ref_g).max() <= 1e-5 * np.abs(ref_g).max(), (form, float(np.abs(g - ref_g).max()))
+    finally:
+        ops.set_precision('bf16')

@@ -20,6 +20,16 @@ for tag, T, I in (('l0', 1200, 80), ('l1', 600, 1280), ('l2', 300, 1280), ('l3',
     SHAPES.append((f'{tag} dW_hh  A^T*B', True, False, 1280, 320, T * B))
 
 
+if os.environ.get('SHAPES') == 'c5':      # the 6x1024 BiLSTM of BASELINE configs[4]: 4H*ND = 8192 gate columns, 4096- / 2048-wide inputs
+    SHAPES = []
+    for tag, T, I in (('l0', 1200, 80), ('l1', 600, 4096), ('l2', 300, 4096), ('l3', 300, 2048)):
+        SHAPES.append((f'{tag} xproj  A*B^T', False, True, T * B, 8192, I))
+        if tag != 'l0':
+            SHAPES.append((f'{tag} dX     A*B  ', False, False, T * B, I, 8192))
+        SHAPES.append((f'{tag} dW_ih  A^T*B', True, False, 8192, I, T * B))
+        SHAPES.append((f'{tag} dW_hh  A^T*B', True, False, 4096, 1024, T * B))
+
+
 def main():
     dev = torch.device('cuda:0')
     ops.set_precision('bf16') if hasattr(ops, 'set_precision') else None

@@ -716,10 +716,14 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     if (loc && AI > 8) return LAS_E_UNSUPPORTED;
     const bool chain = parts & LAS_DEC_BWD_CHAIN, sums = parts & LAS_DEC_BWD_PARAM_SUMS;
     if (loc) LAS_CHECK_ARG(w.df && w.de && w.dpsi && w.acc);
+    // one persistent launch for the whole sequential chain when the shape / mode allows it and the caller gave the workspace
+    const bool pk = w.pk_ws && w.pk_status && las_dec_pk_bwd_ws_bytes(d) > 0;
     if (chain) {
-        LAS_HIP(hipMemsetAsync(w.dh_carry, 0, sizeof(float) * NL * BC, st));
-        LAS_HIP(hipMemsetAsync(w.dc_carry, 0, sizeof(float) * NL * BC, st));
-        LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
+        if (!pk) {       // (the persistent loop keeps the carries in registers and writes every element of d q_pre itself)
+            LAS_HIP(hipMemsetAsync(w.dh_carry, 0, sizeof(float) * NL * BC, st));
+            LAS_HIP(hipMemsetAsync(w.dc_carry, 0, sizeof(float) * NL * BC, st));
+            LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
+        }
         if (loc) {
             LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
             LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
@@ -733,8 +737,6 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
     const bool fuse_pw = NL == 1;
     const bool drop = d->dropout > 0.f;
-    // one persistent launch for the whole sequential chain when the shape / mode allows it and the caller gave the workspace
-    const bool pk = w.pk_ws && w.pk_status && las_dec_pk_bwd_ws_bytes(d) > 0;
     if (pk && chain) {
         int rc = las_dec_pk_bwd(d, p, enc, enc_len, st_, g_htop, bw_, st);
         if (rc) return rc;

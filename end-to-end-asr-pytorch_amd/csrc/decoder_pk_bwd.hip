@@ -62,7 +62,7 @@ struct PbArgs {
     // outputs (las_dec_bwd_state)
     float* dgates; float* dxin; float* dq_pre; float* de; float* df;
     // exchange rings (2 slots each)
-    void* px;                           // [2][NCT][B][NX] compute type: K-split pieces
+    void* px;                           // [2][NCT][B][NX / V8] 16-byte granules {V8 values of a K-split piece (4 bf16 | 2 f32), 0, tag = step count}
     float* dax;                         // [2][B][NCH][Tp]
     float* dqx;                         // [2][B][NCH][Ap]
     float* dfx;                         // [2][B][10][Tp]
@@ -142,7 +142,6 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
     T* Ql = WqT + 16 * ldq;                             // [NB*16][ldq] d q_pre rows of my batch slice
     T* Pl = Ql + NB * 16 * ldq;                         // [NCT][NB*16][U] pieces addressed to me
     float* Gl = (float*)(Pl + (size_t)g.NCT * NB * 16 * U);      // [PNW][NB*16][17]
-    int* flag = (int*)(Gl + PNW * NB * 16 * 17);
 
     for (int i = threadIdx.x; i < NX * ldk; i += PNT) {
         const int k = i % ldk, n = i / ldk, gi = k / U, u = k - gi * U;
@@ -167,8 +166,6 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
     float dc_carry = 0.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
     unsigned* abort_word = a.sync->abort_;
-    unsigned nwait = 0;
-    T* px = (T*)a.px;
     PK_STAMP_DECL;
 
     for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
@@ -184,19 +181,28 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
         PK_STAMP(0);
         if (t + 1 < a.L) {
             // ---- recurrent d h_t = sum of the pieces of step t+1 addressed to my units + d q_pre_{t+1} W_phi
-            if (!pk_block_wait(&a.sync->cnt_p[bs][0], 0, 1, (unsigned)g.NCT * (n - 1), abort_word, flag + (nwait++ & 1))) {
-                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-                return;
-            }
+            // (tagged granules, as d q_pre below: the pieces of step t+1 were stored long ago, the first pass matches)
             {
-                const int vpr = U / VEC > 0 ? U / VEC : 1;          // 16-byte vectors per (producer, row)
-                const T* src = px + ((size_t)((t + 1) & 1) * g.NCT * B) * NX;
-                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.NCT * B * NX * (int)sizeof(T), 0x00020000);
-                for (int i = threadIdx.x; i < g.NCT * Bl * vpr; i += PNT) {
-                    const int pj = i / (Bl * vpr), rem = i - pj * (Bl * vpr), r = rem / vpr, v = rem - r * vpr;
-                    const int off = (((pj * B) + b0 + r) * NX + E + j0 + v * VEC) * (int)sizeof(T);
-                    const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-                    *(u32x4*)(Pl + ((size_t)pj * NB * 16 + r) * U + v * VEC) = val;
+                constexpr int V8 = GrT<T>::V8;
+                const int NGX = NX / V8, gpr = U / V8, total = g.NCT * Bl * gpr;
+                __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.px + (size_t)((t + 1) & 1) * g.NCT * B * NGX * 16), 0,
+                                                                             g.NCT * B * NGX * 16, 0x00020000);
+                auto sweep = [&](auto swv) -> bool {
+                    constexpr int SW = decltype(swv)::value;
+                    int off[SW], dst[SW];
+#pragma unroll
+                    for (int u = 0; u < SW; ++u) {
+                        const int i = threadIdx.x + u * PNT, pj = i / (Bl * gpr), rem = i - pj * (Bl * gpr), r = rem / gpr, gc = rem - r * gpr;
+                        off[u] = i < total ? ((pj * B + b0 + r) * NGX + (E + j0) / V8 + gc) * 16 : GR_OOB;
+                        dst[u] = (pj * NB * 16 + r) * U + gc * V8;
+                    }
+                    return pk_gr_sweep<SW>(rp, off, (unsigned)(n - 1), abort_word, [&](int u, const u32x4& gv) { pk_gr_scatter<T, 2>(Pl + dst[u], gv); });
+                };
+                const bool ok = total <= 2 * PNT ? sweep(std::integral_constant<int, 2>{}) : total <= 4 * PNT ? sweep(std::integral_constant<int, 4>{})
+                                                                                                             : sweep(std::integral_constant<int, 8>{});
+                if (!ok) {
+                    if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                    return;
                 }
             }
             PK_STAMP(1);
@@ -263,18 +269,27 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
         // ---- K-split product: my d gates slice x my rows of [W_ih(ctx) | W_hh], transposed so that a lane ends up with 4
         // consecutive output columns of one batch row (one 8-byte store per tile)
         {
-            T* dst = px + ((size_t)(t & 1) * g.NCT + j) * B * NX;
+            constexpr int V8 = GrT<T>::V8;
+            const int NGX = NX / V8;
+            __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.px + ((size_t)(t & 1) * g.NCT + j) * B * NGX * 16), 0,
+                                                                         B * NGX * 16, 0x00020000);
             for (int tile = wave; tile < NTN; tile += PNW) {
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
                     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
                     mma_rows<PREC, 1>(acc, WT + (size_t)tile * 16 * ldk, ldk, Dl + bt * 16 * ldk, ldk, NKS);
-                    const int row = bt * 16 + fr;
-                    if (row < Bl) st4_sc1(dst + (size_t)(b0 + row) * NX + tile * 16 + fq * 4, acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                    // a lane's four columns of one batch row leave as tagged granules: payload + step count in ONE 16-byte sc1
+                    // store (bf16: one granule; f32: two), no drain, barrier or counter behind them
+                    const int row = bt * 16 + fr, g0 = ((b0 + row) * NGX + (tile * 16 + fq * 4) / V8) * 16;
+                    if constexpr (PREC == LAS_PREC_BF16) {
+                        pk_gr_store(rp, row < Bl ? g0 : GR_OOB, pack_bf16x2(acc[0][0], acc[0][1]), pack_bf16x2(acc[0][2], acc[0][3]), 0u, (unsigned)n);
+                    } else {
+                        pk_gr_store(rp, row < Bl ? g0 : GR_OOB, __float_as_uint(acc[0][0]), __float_as_uint(acc[0][1]), 0u, (unsigned)n);
+                        pk_gr_store(rp, row < Bl ? g0 + 16 : GR_OOB, __float_as_uint(acc[0][2]), __float_as_uint(acc[0][3]), 0u, (unsigned)n);
+                    }
                 }
             }
         }
-        pk_signal(&a.sync->cnt_p[bs][0]);
         PK_STAMP(4);
         if (ev) {
             float* go = a.dgates + ((long)t * B + b0 + er) * 4 * C;
@@ -307,7 +322,6 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         else { b = id / g.NCH; c = id - b * g.NCH; }
     }
     if (b >= a.B) return;
-    const int bs = b / g.Bs;
     const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E, Ap = g.Ap, NX = g.NX;
     const int len = a.lens[b];
     const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0)), tcv = max(0, min(TCr, len - r0));
@@ -380,7 +394,6 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         return;
     }
     const bool local = loc_ > 0;            // my utterance's parts share an XCD: L2-local exchanges among them
-    T* px = (T*)a.px;
     const int cv_sg = threadIdx.x / (LOC_C * TCq), cv_cc = (threadIdx.x - cv_sg * (LOC_C * TCq)) / TCq,
               cv_qd = threadIdx.x - cv_sg * (LOC_C * TCq) - cv_cc * TCq;
     // window origin: dfn_l[cc][x] = d f_next[cc][r0 - LOC_K - sh + x], sh chosen so that frame r0's window start is 16-byte aligned
@@ -480,51 +493,68 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         }
         __syncthreads();
         PK_STAMP(18);
-        load_s(t);                      // in flight during the u recompute and the wait for the pieces; first used in phase E
         PK_STAMP(0);
         // 1 - u^2 of my elements (u = tanh(F W_lp^T) on the MFMA), kept in registers
-        float um[MT][NTW][4];
+        // (bf16 mode: kept as bf16 PAIRS, 18 registers instead of 36 -- d u = d z (1 - u^2) is rounded to bf16 for the d f product
+        // anyway; the registers are what lets the piece sweep below run without scratch spills)
+        constexpr int UMW = PREC == LAS_PREC_BF16 ? 2 : 4;
+        unsigned um[MT][NTW][UMW];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
                 mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
+                float uu[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float u = fast_tanh(acc[0][r]);
-                    um[mt][j][r] = 1.f - u * u;
-                    asm volatile("" : "+v"(um[mt][j][r]));
+                    uu[r] = 1.f - u * u;
                 }
+                if constexpr (PREC == LAS_PREC_BF16) {
+                    um[mt][j][0] = pack_bf16x2(uu[0], uu[1]);
+                    um[mt][j][1] = pack_bf16x2(uu[2], uu[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) um[mt][j][r] = __float_as_uint(uu[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < UMW; ++r) asm volatile("" : "+v"(um[mt][j][r]));
             }
         PK_STAMP(1);
         // ---- (B) d ctx of my E-slice: sum of the cell role's pieces of this step
-        if (!pk_block_wait(&a.sync->cnt_p[bs][0], 0, 1, (unsigned)g.NCT * n, abort_word, flag + (nwait++ & 1))) {
-            if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
-            return;
-        }
         PK_STAMP(2);
         {
-            // one 16-byte sc1 load per (producer, column vector) -> psum_l[producer][ES] (fp32, in the scratch region, free
-            // between the conv path and the d u tile); then thread (column, quarter of the producers), then 4 partials.
-            // (LDS float atomics instead: 12 900 cycles -- they retire about one LANE per 3 cycles, cycle stamps)
+            // the pieces arrive as tagged granules: the sweep is wait and pull in one (one L2 round trip once the last cell has
+            // stored); a matched granule goes to psum_l[producer][ES] as fp32 (in the scratch region, free between the conv path
+            // and the d u tile); then thread (column, quarter of the producers), then 4 partials.  ONE granule per lane and pass
+            // over the list: two at once cost registers the role does not have here (it holds 1 - u^2 of its 36 elements).
+            // (LDS float atomics for the sums instead: 12 900 cycles -- they retire about one LANE per 3 cycles, cycle stamps)
             float* psum_l = dfn_l;                                           // [NCT][ES]
-            const int nv = ES / VEC;
-            const T* src = px + (size_t)(t & 1) * g.NCT * B * NX;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, g.NCT * B * NX * (int)sizeof(T), 0x00020000);
-            for (int i = threadIdx.x; i < g.NCT * nv; i += PNT) {
-                const int pj = i / nv, v = i - pj * nv, col = e0 + v * VEC;
-                u32x4 raw = {0u, 0u, 0u, 0u};
-                if (col < E) raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (((pj * B + b) * NX) + col) * (int)sizeof(T), 0, 16);
-                float* o = psum_l + pj * ES + v * VEC;
-                if constexpr (PREC == LAS_PREC_BF16) {
-                    *(float4*)o = make_float4(__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u),
-                                              __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u));
-                    *(float4*)(o + 4) = make_float4(__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u),
-                                                    __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u));
-                } else {
-                    *(u32x4*)o = raw;
+            constexpr int V8 = GrT<T>::V8;
+            const int NGX = NX / V8, gpe = ES / V8, total = g.NCT * gpe;
+            __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.px + (size_t)(t & 1) * g.NCT * B * NGX * 16), 0,
+                                                                         g.NCT * B * NGX * 16, 0x00020000);
+            bool ok = true;
+            for (int i0 = 0; i0 < total && ok; i0 += PNT) {
+                const int i = i0 + threadIdx.x, pj = i / gpe, gc = i - pj * gpe, col = e0 + gc * V8, dst = pj * ES + gc * V8;
+                int off[1] = {(i < total && col < E) ? ((pj * B + b) * NGX + col / V8) * 16 : GR_OOB};
+                if (i < total && col >= E) {                                 // beyond E (last part): not d ctx columns, zeros
+#pragma unroll
+                    for (int e = 0; e < V8; ++e) psum_l[dst + e] = 0.f;
                 }
+                ok = pk_gr_sweep<1>(rp, off, (unsigned)n, abort_word, [&](int, const u32x4& gv) {
+                    float* o = psum_l + dst;
+                    if constexpr (PREC == LAS_PREC_BF16)
+                        *(float4*)o = make_float4(__uint_as_float(gv[0] << 16), __uint_as_float(gv[0] & 0xffff0000u),
+                                                  __uint_as_float(gv[1] << 16), __uint_as_float(gv[1] & 0xffff0000u));
+                    else
+                        *(float2*)o = make_float2(__uint_as_float(gv[0]), __uint_as_float(gv[1]));
+                });
+            }
+            if (!ok) {
+                if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
+                return;
             }
             __syncthreads();
             float part4 = 0.f;
@@ -537,6 +567,8 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) { dctx_l[threadIdx.x >> 2] = part4; dctxT_l[threadIdx.x >> 2] = to_ct<T>(part4); }
         }
         __syncthreads();
+        load_s(t);                      // requested only now (its 36 registers would be live across the piece sweep): in flight during
+                                        // the d a product, its exchange and the softmax backward; first used in phase E
         PK_STAMP(11);
         // ---- (C) d a over my E-slice for every frame of the utterance (+ the conv path for my own frames)
         // on the matrix cores: A = 16 frames x my slice of enc (LDS), B = the d ctx row for all 16 columns (ldb = 0: every lane of
@@ -601,7 +633,10 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                     const float dz = tt < tcv ? de * wev[j] * (1.f - s_ * s_) : 0.f;
                     dq[j] += dz;
                     const int aa = (wave + PNW * j) * 16 + fr;
-                    if (aa < Ap) Du[tt * lda_ + aa] = to_ct<T>(dz * um[mt][j][r]);
+                    float umv;
+                    if constexpr (PREC == LAS_PREC_BF16) umv = (r & 1) ? __uint_as_float(um[mt][j][r >> 1] & 0xffff0000u) : __uint_as_float(um[mt][j][r >> 1] << 16);
+                    else umv = __uint_as_float(um[mt][j][r]);
+                    if (aa < Ap) Du[tt * lda_ + aa] = to_ct<T>(dz * umv);
                 }
             }
         PK_STAMP(13);
@@ -752,12 +787,11 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
 
 struct PbWs { size_t sync, dbg, px, dax, dqx, dfx, dqq, total; };
 PbWs pb_ws(const las_dec_dims* d, const PbGeom& g) {
-    const size_t sz = d->prec == LAS_PREC_BF16 ? 2 : 4;
     PbWs w;
     size_t o = 0;
     w.sync = o; o += las_align(sizeof(PbSync));
     w.dbg = o; o += las_align(sizeof(unsigned long long) * 256 * 20);
-    w.px = o; o += las_align((size_t)2 * g.NCT * d->B * g.NX * sz);
+    w.px = o; o += las_align((size_t)2 * g.NCT * d->B * (g.NX / (d->prec == LAS_PREC_BF16 ? 4 : 2)) * 16);       // granules of 4 bf16 | 2 f32
     w.dax = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * d->Tp);
     w.dqx = o; o += las_align(sizeof(float) * 2 * d->B * g.NCH * g.Ap);
     w.dfx = o; o += las_align(sizeof(float) * 2 * d->B * LOC_C * ((d->Tp + 3) & ~3));

@@ -1659,7 +1659,8 @@ int launch_fwd_gr(const LstmArgs& a, size_t lds, hipStream_t st, const float* xp
                   SyncWords* sync, int* status) {
     auto k = lstm_fwd_gr_kernel<NB, KS>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    LAS_HIP(hipMemsetAsync(hx, 0, fwd_gr_ring_bytes(a), st));          // tags of earlier launches must not match
+    if ((char*)hx != (char*)sync + sizeof(SyncWords))                    // (else: zeroed together with the sync words by the caller below)
+        LAS_HIP(hipMemsetAsync(hx, 0, fwd_gr_ring_bytes(a), st));      // tags of earlier launches must not match
     hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT + 64), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf,
                        (u32x4*)hx, gates, cs, sync, status);
     LAS_LAUNCH_OK();
@@ -1804,9 +1805,11 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
-    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
+    // one fill for the sync words and, when the caller placed it right behind them, the granule ring
+    const bool gr_fwd = fwd_uses_gr(prec, T, B, H, ND, a, U, NB, KS);
+    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + ((gr_fwd && (char*)hx == (char*)sync + sizeof(SyncWords)) ? fwd_gr_ring_bytes(a) : 0), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
-    if (fwd_uses_gr(prec, T, B, H, ND, a, U, NB, KS)) {
+    if (gr_fwd) {
         // tagged-granule hand-off (lstm_fwd_gr_kernel): no flag, no drain, one barrier per step
         lds = fwd_gr_lds(H, NB);
         if (lds < MIN_LDS) lds = MIN_LDS;
@@ -1844,9 +1847,10 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     a.wdirect = p.wdirect ? 1 : 0;
     const size_t lds = p.lds;
     hipStream_t st = (hipStream_t)stream;
-    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords), st));
+    const bool ring_behind = p.gr && (char*)dgx == (char*)sync + sizeof(SyncWords);      // one fill for both
+    LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + (ring_behind ? p.ws : 0), st));
     if (p.gr) {
-        LAS_HIP(hipMemsetAsync(dgx, 0, p.ws, st));                        // tags of earlier launches must not match
+        if (!ring_behind) LAS_HIP(hipMemsetAsync(dgx, 0, p.ws, st));      // tags of earlier launches must not match
 #define LAS_GR_GO(N_, M_)                                                                                              \
     {                                                                                                                 \
         auto k = lstm_bwd_gr_kernel<N_, M_>;                                                                          \

@@ -521,10 +521,12 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
     esz, vec = (2, 8) if _prec == 0 else (4, 4)
     Hx = (H + vec - 1) // vec * vec
-    hx = (torch.empty if Hx == H else torch.zeros)(L_.las_lstm_hx_bytes(I(_prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
+    # sync words and the exchange buffer in ONE allocation, the buffer right behind the words: the library then zeroes both with one fill
+    nsync, nhx = L_.las_lstm_sync_bytes(), L_.las_lstm_hx_bytes(I(_prec), I(T), I(B), I(H), I(ND))
+    sx = (torch.empty if Hx == H else torch.zeros)(nsync + nhx, dtype=torch.uint8, device=dev)
+    sync, hx = sx[:nsync], sx[nsync:]
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
-    sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
     kname = 'lstm_fwd_gr_kernel' if L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND)) else 'lstm_fwd_kernel'
     with _Timed(kname, 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
@@ -543,9 +545,10 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     ND, H4, H = w_hh.shape
     dev = x.device
     gy = gy.contiguous()
-    dgx = torch.empty(L_.las_lstm_bwd_ws_bytes(I(prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
+    nsync = L_.las_lstm_sync_bytes()
+    sx = torch.empty(nsync + L_.las_lstm_bwd_ws_bytes(I(prec), I(T), I(B), I(H), I(ND)), dtype=torch.uint8, device=dev)
+    sync, dgx = sx[:nsync], sx[nsync:]              # (one allocation, the workspace behind the sync words: one zero fill)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
-    sync = torch.empty(L_.las_lstm_sync_bytes(), dtype=torch.uint8, device=dev)
     ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
     with _Timed(('lstm_bwd_kernel', 'lstm_bwd_ks_kernel', 'lstm_bwd_gr_kernel')[ksplit], 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),

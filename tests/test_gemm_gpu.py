@@ -66,6 +66,17 @@ def test_gemm_batched_and_colsum(ops):
     out = torch.ones(77, device=dev)
     ops.colsum(torch.tensor(X, device=dev), out, beta=2.0)
     np.testing.assert_allclose(out.cpu().numpy(), 2.0 + X.astype(np.float64).sum(0), atol=2e-3)
+    # two outputs in one pass (las_colsum2: bias_ih / bias_hh), beta = 1 (no scale launch), 0 and another value; a strided source
+    Xd = torch.tensor(X, device=dev)
+    for beta in (1.0, 0.0, 0.5):
+        o1, o2 = torch.full((77,), 3.0, device=dev), torch.full((77,), -1.0, device=dev)
+        ops.colsum(Xd, o1, beta=beta, out2=o2)
+        ref = X.astype(np.float64).sum(0)
+        np.testing.assert_allclose(o1.cpu().numpy(), beta * 3.0 + ref, atol=2e-3)
+        np.testing.assert_allclose(o2.cpu().numpy(), beta * -1.0 + ref, atol=2e-3)
+    o1 = torch.zeros(30, device=dev)
+    ops.colsum(Xd[:, 10:40], o1, beta=1.0)                     # ld = 77, N = 30
+    np.testing.assert_allclose(o1.cpu().numpy(), X[:, 10:40].astype(np.float64).sum(0), atol=2e-3)
 
 
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])

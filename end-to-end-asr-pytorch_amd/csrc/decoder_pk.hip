@@ -39,10 +39,12 @@ constexpr int MAXB = 32;
 
 struct PkSync {                         // zeroed before every launch
     unsigned abort_[CLW];
+    unsigned utt[MAXB][CLW];            // per utterance: words 32..34 = the placement rendezvous of its attention parts
 };
 
 struct PkGeom {
     int U, NCT, NS, Bs, NB, NCELL;      // cell role: units per workgroup, unit slices, batch slices, rows per slice, 16-row tiles
+    int xl;                             // attention parts of an utterance on block ids congruent mod 8 (one XCD, observed)
     int NQC;                            // q column tiles (16 wide)
     int NCH, TC, ES;                    // attention role: parts per utterance, frames per part, context columns per part
     int Cp, Ep, Cx, Ex;                 // k extents padded to the MFMA k-step; exchange row strides (padded to a vector)
@@ -273,7 +275,14 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     typedef typename CT<PREC>::T T;
     constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
     const PkGeom& g = a.g;
-    const int id = blockIdx.x - g.NCELL, b = id / g.NCH, c = id - b * g.NCH;
+    // block -> (utterance b, part c); XCD-grouped as in the BPTT loop (decoder_pk_bwd.hip): ids congruent mod 8 share an XCD
+    int b, c;
+    {
+        const int id = blockIdx.x - g.NCELL;
+        if (g.xl) { const int m = id >> 3; b = (m / g.NCH) * 8 + (id & 7); c = m % g.NCH; }
+        else { b = id / g.NCH; c = id - b * g.NCH; }
+    }
+    if (b >= a.B) return;
     const int B = a.B, Tp = a.Tp, E = a.E, A = a.A, C = a.C, XI = C + E;
     const int len = a.lens[b];
     const int TC = g.TC, r0 = c * TC, TCr = max(0, min(TC, Tp - r0));
@@ -330,6 +339,10 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? we_l[aa] : 0.f; }
     const float be = a.b_e[0];
     unsigned* abort_word = a.sync->abort_;
+    // the energies all-gather stays inside my utterance: plain granule stores when its parts share an XCD's L2 (checked once)
+    const int loc_ = pk_utt_local(&a.sync->utt[b][0], g.NCH, g.xl != 0, abort_word, (int*)(red + 64));
+    if (loc_ < 0) { *a.status = LAS_E_TIMEOUT; return; }
+    const bool local = loc_ > 0;
     constexpr int V12 = GrT<T>::V12;
     // my shares of the two sweeps (q of my utterance: QG granules of 2 f32; its energies: NCH * TCG granules of 2 f32)
     constexpr int SWA = 2;
@@ -463,7 +476,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             pk_gr_gather8<float>(v, w2);                         // energies travel in f32: 2 frames per granule
             __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(a.exg + (t & 1) * slot_e), 0, slot_e * 16, 0x00020000);
             // (every part publishes all its TCG granules, zeros beyond the utterance: the readers wait for each of them)
-            pk_gr_store(re, (!(threadIdx.x & 1) && (int)threadIdx.x / 2 < g.TCG) ? ((b * g.NCH + c) * g.TCG + (int)threadIdx.x / 2) * 16 : GR_OOB, w2[0], w2[1], 0u, tag);
+            pk_gr_store_x(re, (!(threadIdx.x & 1) && (int)threadIdx.x / 2 < g.TCG) ? ((b * g.NCH + c) * g.TCG + (int)threadIdx.x / 2) * 16 : GR_OOB, w2[0], w2[1], 0u, tag, local);
         }
         PK_STAMP(3);
         PK_STAMP(4);
@@ -619,6 +632,7 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
         g.TCG = (g.TC + 1) / 2;
         if (g.Bs * g.HG > 4 * PNT || g.Bs * g.NCH * g.CG > 4 * PNT || g.QG > 2 * PNT || g.NCH * g.TCG > 2 * PNT) continue;
         if ((g.ES + 11) / 12 * 16 > PNT) continue;
+        g.xl = (!getenv("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= 256) ? 1 : 0;
         g.lds = cell_lds(d->prec, g, d->C, d->E);
         const size_t al = att_lds(d->prec, g, d->Tp, d->A);
         if (al > g.lds) g.lds = al;
@@ -676,7 +690,7 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     a.hxg = (u32x4*)(ws + w.hxg); a.cxg = (u32x4*)(ws + w.cxg); a.qxg = (u32x4*)(ws + w.qxg); a.exg = (u32x4*)(ws + w.exg);
     a.sync = (PkSync*)(ws + w.sync); a.status = st->pk_status;
     a.dbg = (unsigned long long*)(ws + w.dbg);
-    const int grid = g.NCELL + B * g.NCH;
+    const int grid = g.NCELL + (g.xl ? 8 * ((B + 7) / 8) * g.NCH : B * g.NCH);
 #define LAS_PK_GO(P_, N_, M_, W_)                                                                                  \
     {                                                                                                             \
         auto k = dec_pk_fwd_kernel<P_, N_, M_, W_>;                                                               \

@@ -104,25 +104,6 @@ __device__ __forceinline__ bool pk_block_wait_x(unsigned* line, int nparts, unsi
     return local ? pk_block_wait(line + 1, 1, nparts, steps, abort_word, flag)
                  : pk_block_wait(line, 0, 1, (unsigned)nparts * steps, abort_word, flag);
 }
-// 1: every part of the utterance reported the same hardware XCC id; 0: not (or the id mapping is not the XCD-grouped one);
-// -1: timeout.  One rendezvous before the first step through agent-scope atomics on words 32..34 of the utterance's d a line.
-__device__ __forceinline__ int pb_utt_local(unsigned* line, int nparts, bool try_local, unsigned* abort_word, int* flag) {
-    if (!try_local) return 0;
-    unsigned* w = line + 32;
-    if (threadIdx.x == PNT - 64) {
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        x &= 15u;
-        const unsigned o1 = __hip_atomic_fetch_max(w + 1, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned o2 = __hip_atomic_fetch_max(w + 2, 16u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(o1), "v"(o2) : "memory");          // both maxima performed before the arrival below
-        __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!pk_block_wait(w, 0, 1, (unsigned)nparts, abort_word, flag)) return -1;
-    const unsigned mx = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                   mn = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return mx + mn == 17u ? 1 : 0;
-}
 __device__ __forceinline__ float ct2f(float v) { return v; }
 __device__ __forceinline__ float ct2f(bf16_t v) { return bf2f(v); }
 
@@ -388,7 +369,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? a.w_e[aa] : 0.f; }
     unsigned* abort_word = a.sync->abort_;
     unsigned nwait = 0;
-    const int loc_ = pb_utt_local(&a.sync->cnt_da[b][0], g.NCH, g.xl != 0, abort_word, flag + 2);
+    const int loc_ = pk_utt_local(&a.sync->cnt_da[b][0], g.NCH, g.xl != 0, abort_word, flag + 2);
     if (loc_ < 0) {
         if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
         return;

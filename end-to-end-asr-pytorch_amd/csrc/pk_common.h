@@ -61,6 +61,25 @@ __device__ __forceinline__ void pk_signal(unsigned* cnt) {
     __syncthreads();
     if (threadIdx.x == PNT - 64) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// 1: every part of the utterance reported the same hardware XCC id; 0: not (or the id mapping is not the XCD-grouped one);
+// -1: timeout.  One rendezvous before the first step through agent-scope atomics on words 32..34 of a zeroed 256-byte line of the utterance.
+__device__ __forceinline__ int pk_utt_local(unsigned* line, int nparts, bool try_local, unsigned* abort_word, int* flag) {
+    if (!try_local) return 0;
+    unsigned* w = line + 32;
+    if (threadIdx.x == PNT - 64) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 15u;
+        const unsigned o1 = __hip_atomic_fetch_max(w + 1, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned o2 = __hip_atomic_fetch_max(w + 2, 16u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o1), "v"(o2) : "memory");          // both maxima performed before the arrival below
+        __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!pk_block_wait(w, 0, 1, (unsigned)nparts, abort_word, flag)) return -1;
+    const unsigned mx = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   mn = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return mx + mn == 17u ? 1 : 0;
+}
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -116,6 +135,12 @@ __device__ __forceinline__ bool pk_gr_sweep(__amdgpu_buffer_rsrc_t rs, const int
 __device__ __forceinline__ void pk_gr_store(__amdgpu_buffer_rsrc_t rs, int off, unsigned w0, unsigned w1, unsigned w2, unsigned tag) {
     const u32x4 g = {w0, w1, w2, tag};
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 16);     // sc1: the consumers sit on other XCDs
+}
+// ... or a plain store when producer and consumers share an XCD's L2 (checked at run time, pk_utt_local)
+__device__ __forceinline__ void pk_gr_store_x(__amdgpu_buffer_rsrc_t rs, int off, unsigned w0, unsigned w1, unsigned w2, unsigned tag, bool local) {
+    const u32x4 g = {w0, w1, w2, tag};
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(g, rs, off, 0, 16);
 }
 template <int CTRL>
 __device__ __forceinline__ unsigned pk_dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }

@@ -362,8 +362,9 @@ def test_loc_post_mfma_matches_valu_kernel(mods, B, Tp, E, A, C, V, L):
 
 @pytest.mark.parametrize('B,Tp,E,A,C,V,L', [(24, 300, 640, 300, 320, 31, 6), (16, 77, 96, 130, 64, 17, 5)])
 def test_persistent_bptt_exchange_forms_agree(mods, B, Tp, E, A, C, V, L):
-    """The BPTT loop's exchanges among an utterance's parts: L2-local form (XCD-grouped block ids, plain stores + progress
-    words, taken when the run-time XCC-id check passes) against the sc1 + counter form (LAS_DEC_NO_XL=1).  Same arithmetic in
+    """The persistent loops' exchanges among an utterance's parts (forward: the energies all-gather; BPTT: d a, d q partials, d f):
+    L2-local form (XCD-grouped block ids, plain stores (+ progress words), taken when the run-time XCC-id check passes)
+    against the sc1 form (LAS_DEC_NO_XL=1).  Same arithmetic in
     the same order: every gradient equal to 1e-6 of its largest entry."""
     import os
     ops, dec = mods
@@ -395,7 +396,8 @@ def test_persistent_bptt_exchange_forms_agree(mods, B, Tp, E, A, C, V, L):
             ops.join_side_stream()
             torch.cuda.synchronize()
             assert int(status.item()) == 0
-            res.append(dict({'d enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
+            res.append(dict({'h_top': h_top.detach().cpu().numpy(), 'att': att.detach().cpu().numpy(),        # (the forward loop's energies exchange too)
+                             'd enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
                             **{k: Wg[k].grad.cpu().numpy() for k in names if not k.startswith('char_trans')}))
     finally:
         os.environ.pop('LAS_DEC_NO_XL', None)

@@ -22,7 +22,7 @@ for it in range(3):
     S = dec.decoder_forward_raw(W, enc, psi, lens_t, y, L, 1, True)
     e1.record(); torch.cuda.synchronize()
 print('forward %.3f ms = %.2f us/step' % (e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / L), 'status', int(S['pk_status'].item()))
-sync_bytes = 256                                 # PkSync = the abort line only
+sync_bytes = 256 * (1 + 32)                      # PkSync = the abort line + one rendezvous line per utterance (MAXB = 32)
 dbg = S['pk_ws'][sync_bytes:sync_bytes + 256 * 20 * 8].view(torch.int64).view(256, 20).cpu().numpy().astype(np.float64) / L
 rows = dbg[dbg.sum(1) > 0]
 ncell = int(os.environ.get('NCELL', 80))

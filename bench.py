@@ -2,7 +2,8 @@
 """Headline benchmark: real mel-frames/s of the full LAS+CTC train step (forward -> joint CTC + CE loss -> backward ->
 gradient all-reduce -> clip -> optimiser) on synthetic 80-dim fbank batches.
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W      (N>1: one rank per GPU; under torch.distributed.run the ranks are
+  the launcher's, otherwise bench.py starts them itself as a child `python -m torch.distributed.run ... bench.py`)
 
 Workloads: c3 (default; BASELINE.json configs[2], the config the metric "LAS+CTC" is quoted on:
 LibriSpeech-100h hybrid CTC+attention, ctc_weight 0.5, bf16, 1 GPU), c2 (configs[1]: the same model attention-only), c4
@@ -132,6 +133,37 @@ def attach_pmc_traffic(roof, workload):
             row['traffic_stale'] = stale
 
 
+def launch_ranks_if_needed(a):
+    """`python bench.py --gpus N` with no torchrun environment starts the N ranks itself: a CHILD process
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` (one rank per GPU over RCCL),
+    whose rank 0 prints the JSON line on the inherited stdout; this process only waits and exits with the child's code.
+    Nothing here touches the GPU (the parent never initialises HIP: `torch.cuda.device_count()` does not on this stack).
+    Refuses, with a non-zero exit, a rank count the node cannot give one GPU each (RCCL rejects two ranks on one device);
+    LAS_DIST_BACKEND=gloo lifts that for a rehearsal of the host logic on fewer GPUs."""
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is not None:
+        if int(env_world) != a.gpus:
+            print(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}', file=sys.stderr)
+            sys.exit(2)
+        return
+    if a.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus and os.environ.get('LAS_DIST_BACKEND', 'nccl') == 'nccl':
+        print(f'bench.py: --gpus {a.gpus} asked for, {have} visible: one rank per GPU is required over RCCL '
+              '(LAS_DIST_BACKEND=gloo rehearses the host logic on fewer GPUs)', file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note('starting %d ranks: %s' % (a.gpus, ' '.join(cmd)))
+    sys.exit(subprocess.call(cmd))
+
+
 def note(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -148,6 +180,7 @@ def main():
     ap.add_argument('--cpu-sample-b', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=1)
     a = ap.parse_args()
+    launch_ranks_if_needed(a)
     w = WORKLOADS[a.workload]
     cfg = model_cfg(w)
 
@@ -156,7 +189,9 @@ def main():
     synth = importlib.import_module('end-to-end-asr-pytorch_amd.synth')
     ldist = importlib.import_module('end-to-end-asr-pytorch_amd.dist')
     world, rank, local = ldist.init()
-    assert world == a.gpus or world == 1, (world, a.gpus)
+    if world != a.gpus:                    # never report n_gpus = 1 for a run that was asked for N ranks
+        print(f'bench.py: --gpus {a.gpus} but {world} rank(s) are running', file=sys.stderr)
+        sys.exit(2)
     tmp = tempfile.mkdtemp(prefix='las_bench_')
     tr = time_reduction(w)
     config = dict(asr_model=cfg, clm=dict(enable=False),

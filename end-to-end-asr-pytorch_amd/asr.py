@@ -172,6 +172,12 @@ class Seq2Seq(nn.Module):
         off, k, _ = self.param_slices[f'{prefix}.{kind}_l0']
         return (self.flat_params16 if shadow else self.flat_grads if grads else self.flat_params)[off:off + k * self.ND].view(shape)
 
+    def grad_ready_offsets(self):
+        """Flat-gradient offsets at which backward reports "everything from here on is final" (ops._GRAD_READY, fired by
+        each encoder layer's BPTT node with its first gradient view), in the order backward fires them: top layer first.
+        dist.exchange_without_backward replays them on a rank that has no backward to run."""
+        return [self.param_slices[f'encoder.layer{l}.layer.weight_ih_l0'][0] for l in reversed(range(len(self.dims)))]
+
     def sync_bf16(self):
         """Refresh the weights' bf16 shadow after the fp32 weights were written by anything but the fused optimiser."""
         if self.flat_params.is_cuda:
@@ -280,6 +286,7 @@ class Seq2Seq(nn.Module):
                     ctc_output = ops.linear(enc, self.P('ctc_layer.weight'), self.P('ctc_layer.bias'))
                 enc.record_stream(cs)
                 ctc_output._branch = cs
+                ops._BRANCH['pending'] = cs          # (joint_loss joins this stream even if the tag above gets lost)
             else:
                 ctc_output = ops.linear(enc, self.P('ctc_layer.weight'), self.P('ctc_layer.bias'))
         if self.joint_att:

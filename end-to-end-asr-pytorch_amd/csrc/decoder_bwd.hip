@@ -834,7 +834,7 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
         q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
-        const int no_mma = getenv("LAS_LOC_POST_VALU") ? 1 : 0;         // (tests compare the two kernels; read per call)
+        const int no_mma = las_fallback("LAS_LOC_POST_VALU") ? 1 : 0;         // (tests compare the two kernels; read per call)
         if (prec == LAS_PREC_BF16 && !no_mma) {
             const int ntiles = (A + 15) / 16, NW = ntiles <= 20 ? 4 : 8, NT = (ntiles + NW - 1) / NW;
             const dim3 grid((Tp + 15) / 16, B, L >= 48 ? 3 : 1), blk(64 * NW);

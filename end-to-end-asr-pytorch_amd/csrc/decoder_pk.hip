@@ -591,10 +591,10 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
     if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
     if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
     if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
-    if (getenv("LAS_DEC_NO_PK")) return false;
+    if (las_fallback("LAS_DEC_NO_PK")) return false;
     const int ks = d->prec == LAS_PREC_BF16 ? 32 : 16, vec = d->prec == LAS_PREC_BF16 ? 8 : 4;
     int want_ns = 0, want_u = 0;
-    if (const char* e = getenv("LAS_DEC_PK_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);     // (A/B measurements)
+    if (const char* e = LAS_AB_KNOB("LAS_DEC_PK_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);     // (A/B measurements)
     static const int cand[6][2] = {{2, 8}, {2, 16}, {1, 8}, {1, 16}, {2, 4}, {1, 4}};
     for (int ci = 0; ci < 6; ++ci) {
         PkGeom g{};
@@ -612,7 +612,7 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
         g.Cp = (d->C + ks - 1) / ks * ks; g.Ep = (d->E + ks - 1) / ks * ks;
         g.Cx = (d->C + vec - 1) / vec * vec; g.Ex = (d->E + vec - 1) / vec * vec;
         if (cell_lds(d->prec, g, d->C, d->E) > PK_LDS_CAP) continue;
-        g.NCH = (256 - g.NCELL) / d->B;
+        g.NCH = (las_cu_count() - g.NCELL) / d->B;
         if (g.NCH > 16) g.NCH = 16;
         if (g.NCH < 1) continue;
         g.TC = (d->Tp + g.NCH - 1) / g.NCH;
@@ -632,7 +632,7 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
         g.TCG = (g.TC + 1) / 2;
         if (g.Bs * g.HG > 4 * PNT || g.Bs * g.NCH * g.CG > 4 * PNT || g.QG > 2 * PNT || g.NCH * g.TCG > 2 * PNT) continue;
         if ((g.ES + 11) / 12 * 16 > PNT) continue;
-        g.xl = (!getenv("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= 256) ? 1 : 0;
+        g.xl = (!las_fallback("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= las_cu_count()) ? 1 : 0;
         g.lds = cell_lds(d->prec, g, d->C, d->E);
         const size_t al = att_lds(d->prec, g, d->Tp, d->A);
         if (al > g.lds) g.lds = al;

@@ -719,10 +719,10 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
     if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
     if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
     if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
-    if (getenv("LAS_DEC_NO_PK") || getenv("LAS_DEC_NO_PK_BWD")) return false;
+    if (las_fallback("LAS_DEC_NO_PK") || LAS_AB_KNOB("LAS_DEC_NO_PK_BWD")) return false;
     const int ks = d->prec == LAS_PREC_BF16 ? 32 : 16, vec = d->prec == LAS_PREC_BF16 ? 8 : 4;
     int want_ns = 0, want_u = 0;
-    if (const char* e = getenv("LAS_DEC_PKB_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);      // (A/B measurements)
+    if (const char* e = LAS_AB_KNOB("LAS_DEC_PKB_CFG")) sscanf(e, "%d,%d", &want_ns, &want_u);      // (A/B measurements)
     static const int cand[4][2] = {{2, 8}, {1, 8}, {2, 16}, {1, 16}};
     for (int ci = 0; ci < 4; ++ci) {
         PbGeom g{};
@@ -740,7 +740,7 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
         g.Ap = (d->A + ks - 1) / ks * ks;
         if ((g.U * (d->prec == LAS_PREC_BF16 ? 2 : 4)) % 16 || d->E % vec) continue;     // piece pulls are 16-byte vectors
         if (pb_cell_lds(d->prec, g) > PK_LDS_CAP) continue;
-        g.NCH = (256 - g.NCELL) / d->B;
+        g.NCH = (las_cu_count() - g.NCELL) / d->B;
         if (g.NCH > 16) g.NCH = 16;
         if (g.NCH < 1) continue;
         g.TC = ((d->Tp + g.NCH - 1) / g.NCH + 3) / 4 * 4;         // chunks start on multiples of 4 frames (16-byte window loads)
@@ -755,7 +755,7 @@ bool pb_geom(const las_dec_dims* d, PbGeom& best) {
         if (pb_att_lds(d->prec, g, d->Tp, d->A) > PK_LDS_CAP) continue;
         // XCD-grouped attention blocks: utterance b on the ids == b (mod 8) behind the cells (NCELL a multiple of 8), if the
         // padded grid still is one workgroup per CU
-        g.xl = (!getenv("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= 256) ? 1 : 0;
+        g.xl = (!las_fallback("LAS_DEC_NO_XL") && g.NCELL % 8 == 0 && g.NCELL + 8 * ((d->B + 7) / 8) * g.NCH <= las_cu_count()) ? 1 : 0;
         g.lds = pb_cell_lds(d->prec, g);
         const size_t al = pb_att_lds(d->prec, g, d->Tp, d->A);
         if (al > g.lds) g.lds = al;

@@ -264,7 +264,7 @@ static int gemm_common(int prec, int transA, int transB, int M, int N, int K, fl
     const bool vec = vecA && vecB && K >= 8 && M >= 8 && N >= 8;
     if ((a16 || b16) && (!vec || prec != LAS_PREC_BF16)) return LAS_E_UNSUPPORTED;       // (the caller falls back to its fp32 copy)
     hipStream_t st = (hipStream_t)stream;
-    static const int swz_env = getenv("LAS_GEMM_NOSWZ") ? 0 : 1;
+    static const int swz_env = LAS_AB_KNOB("LAS_GEMM_NOSWZ") ? 0 : 1;
     if (ksplit > 1) grid.z = ksplit;
     const int swz = swz_env && (long)grid.x * grid.y * grid.z >= 16;
     if (ksplit > 1 && beta != 1.f) {               // (beta = 1: the slices are added to what is there)

@@ -132,3 +132,28 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsig
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA bf16 A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 accumulator fragment
+
+// ---- run-time switches.  The product library reads only the documented FALLBACKS (README: LAS_LSTM_NO_XL, LAS_LSTM_NO_GR,
+// LAS_DEC_NO_PK, LAS_DEC_NO_XL, LAS_LOC_POST_VALU): each selects an older, independently tested kernel form, which the parity
+// tests also run.  A/B measurement knobs exist in the diagnostic build only (`make stamps`, -DLAS_DIAG): in liblas_hip.so
+// LAS_AB_KNOB(...) is a compile-time nullptr and the environment is not consulted.
+#include <cstdlib>
+static inline const char* las_fallback(const char* name) { return getenv(name); }
+// CUs of the current device (cached).  The persistent kernels need every workgroup co-resident, one per CU: their geometry
+// is sized from this, never from a literal 256 -- on a partitioned or smaller device a grid that does not fit would spin
+// until its timeout instead of taking the per-step path.  (The XCD-grouping arithmetic still assumes 8 XCDs of CUs/8; the
+// kernels verify placement at run time and fall back to the placement-independent protocol.)
+static inline int las_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else return 256;                 // (no device: size queries made without a GPU answer for an MI355X)
+    }
+    return n;
+}
+#ifdef LAS_DIAG
+#define LAS_AB_KNOB(name) getenv(name)
+#else
+#define LAS_AB_KNOB(name) ((const char*)nullptr)
+#endif

@@ -1615,7 +1615,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
         const int ns6 = (B + 5) / 6;
         ns = ns6 < 8 / ND ? (ns6 > ns ? ns6 : ns) : 8 / ND;
     }
-    while (ns > 1 && ((long)ND * a.G * ns > 256 || ns > MAX_SLICES)) --ns;
+    while (ns > 1 && ((long)ND * a.G * ns > las_cu_count() || ns > MAX_SLICES)) --ns;
     a.Bs = (B + ns - 1) / ns;
     a.NS = (B + a.Bs - 1) / a.Bs;
     a.sr = sr; a.concat = concat;
@@ -1624,12 +1624,12 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
     a.y_is_hf = 0; a.wdirect = 0;
     // XCD-grouped launch when every XCD (32 CUs, one workgroup per CU) can hold the groups dealt to it
-    const bool no_xl = getenv("LAS_LSTM_NO_XL") != nullptr;
+    const bool no_xl = las_fallback("LAS_LSTM_NO_XL") != nullptr;
     const int groups = ND * a.NS, gpl = (groups + 7) / 8;
-    a.xl = (!no_xl && a.G * gpl <= 32) ? 1 : 0;
-    const bool no_nt = getenv("LAS_LSTM_NO_NT") != nullptr;
+    a.xl = (!no_xl && a.G * gpl <= las_cu_count() / 8) ? 1 : 0;
+    const bool no_nt = LAS_AB_KNOB("LAS_LSTM_NO_NT") != nullptr;
     a.nt = no_nt ? 0 : 1;
-    const bool no_pf = getenv("LAS_LSTM_NO_PF") != nullptr;
+    const bool no_pf = LAS_AB_KNOB("LAS_LSTM_NO_PF") != nullptr;
     a.pf = no_pf ? 0 : 1;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
@@ -1683,18 +1683,18 @@ int launch_bwd(const LstmArgs& a, int NC, int K4p, size_t lds, hipStream_t st, c
 struct BwdPlan { bool ks, wdirect, gr; int NB, NC, K4p; size_t lds, ws; };
 int bwd_plan(int prec, int T, int B, int H, int ND, const LstmArgs& a, BwdPlan& p) {
     p.NB = las_pick_nb(a.Bs);
-    if (p.NB == 0 || ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    if (p.NB == 0 || ND * ((H + 15) / 16) > las_cu_count()) return LAS_E_UNSUPPORTED;
     // K-split exchange (reduce-scatter of partial dh) whenever it fits: the [H][64] weight slab in LDS, or (bf16) the
     // weight fragments fetched from global memory into registers (ceil(G / 4) <= 16 tiles per wave: H <= 1024)
     p.ks = false; p.wdirect = false;
-    if (p.NB <= 2 && !getenv("LAS_LSTM_BWD_GATHER")) {
+    if (p.NB <= 2 && !LAS_AB_KNOB("LAS_LSTM_BWD_GATHER")) {
         const int mt = (a.G + 3) / 4;
         if (bwd_ks_lds(prec, H, p.NB, false) <= LDS_CAP && (prec != LAS_PREC_BF16 || mt <= 16)) p.ks = true;
         else if (prec == LAS_PREC_BF16 && mt <= 16 && bwd_ks_lds(prec, H, p.NB, true) <= LDS_CAP) p.ks = p.wdirect = true;
     }
     // tagged-granule hand-off (lstm_bwd_gr_kernel): bf16, <= 8 consumers per wave, <= 1 024 granules per inbox and step
     p.gr = p.ks && prec == LAS_PREC_BF16 && (a.G + 3) / 4 <= 8 && H % 4 == 0 && (long)a.G * a.Bs * 4 <= 1024 &&
-           (long)T * B * ND * 4 * H * 4 < (1l << 31) && bwd_gr_lds(H, p.NB) <= LDS_CAP && !getenv("LAS_LSTM_NO_GR");
+           (long)T * B * ND * 4 * H * 4 < (1l << 31) && bwd_gr_lds(H, p.NB) <= LDS_CAP && !las_fallback("LAS_LSTM_NO_GR");
     if (p.gr) {
         p.wdirect = false;
         p.lds = bwd_gr_lds(H, p.NB);
@@ -1754,20 +1754,28 @@ extern "C" int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND) {
     return p.gr ? 2 : p.ks ? 1 : 0;
 }
 
+extern "C" int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND) {
+    LstmArgs a;
+    (void)prec;
+    if (check_common(T, B, H, ND, 1)) return 0;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    return a.ND * a.G * a.NS;            // (an XCD-grouped launch starts more, the ones without a group exit at once)
+}
+
 // 1: lstm_fwd_gr_kernel (tagged-granule hand-off), 0: lstm_fwd_kernel.  Same rule as in las_lstm_rec_fwd below.
 static bool fwd_uses_gr(int prec, int T, int B, int H, int ND, const LstmArgs& a, int U, int NB, int KS) {
     return prec == LAS_PREC_BF16 && KS > 0 && KS <= 16 && U == 16 && H % 4 == 0 && (long)T * B * ND * 4 * H * 4 < (1l << 31) &&
-           (long)H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6) <= 1024 && !getenv("LAS_LSTM_NO_GR");
+           (long)H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6) <= 1024 && !las_fallback("LAS_LSTM_NO_GR");
 }
 extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
-    if (check_common(T, B, H, ND, 1) || ND * ((H + 15) / 16) > 256) return 0;
+    if (check_common(T, B, H, ND, 1) || ND * ((H + 15) / 16) > las_cu_count()) return 0;
     fill_args(a, T, B, H, ND, 16, 1, 0);
     const int NB = las_pick_nb(a.Bs), ksteps = (H + 31) / 32;
     int KS = 0;
-    if (prec == LAS_PREC_BF16 && NB >= 1 && NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT"))
+    if (prec == LAS_PREC_BF16 && NB >= 1 && NB <= 2 && !LAS_AB_KNOB("LAS_LSTM_NO_DIRECT"))
         KS = ksteps <= 8 ? 8 : ksteps <= 10 ? 10 : (ksteps <= 16 && NB == 1) ? 16 : 0;
-    const bool u8 = !a.xl && ND * ((H + 7) / 8) <= 256 && H == 512;
+    const bool u8 = !a.xl && ND * ((H + 7) / 8) <= las_cu_count() && H == 512;
     return fwd_uses_gr(prec, T, B, H, ND, a, u8 ? 8 : 16, NB, KS) ? 1 : 0;
 }
 
@@ -1779,11 +1787,11 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     if (rc) return rc;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     int U = 16;
-    if (ND * ((H + 15) / 16) > 256) return LAS_E_UNSUPPORTED;
+    if (ND * ((H + 15) / 16) > las_cu_count()) return LAS_E_UNSUPPORTED;
     // use more, smaller unit slices when the chip has room (shorter MFMA chains per step)
     LstmArgs a;
     fill_args(a, T, B, H, ND, U, sr, concat);
-    if (!a.xl && ND * ((H + 7) / 8) <= 256 && H >= 512 && H <= 512) {      // (an XCD-grouped launch beats the finer slicing;
+    if (!a.xl && ND * ((H + 7) / 8) <= las_cu_count() && H >= 512 && H <= 512) {      // (an XCD-grouped launch beats the finer slicing;
         U = 8;                                                            // beyond 512 two batch slices of 16-unit groups do)
         fill_args(a, T, B, H, ND, U, sr, concat);
     }
@@ -1793,7 +1801,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     // 4 KS for the weights + the h fragments of a chunk); otherwise the weight slab lives in LDS
     const int ksteps = (H + 31) / 32;
     int KS = 0;
-    if (prec == LAS_PREC_BF16 && NB <= 2 && !getenv("LAS_LSTM_NO_DIRECT")) {
+    if (prec == LAS_PREC_BF16 && NB <= 2 && !LAS_AB_KNOB("LAS_LSTM_NO_DIRECT")) {
         if (ksteps <= 8) KS = 8;
         else if (ksteps <= 10) KS = 10;
         else if (ksteps <= 16 && NB == 1) KS = 16;
@@ -1885,7 +1893,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
 #define LAS_BWD_ARGS a, NC, K4p, lds, st, dy, gates, cs, w_hh, lens, dgx, dgf, (SyncWords*)sync, status
     if (prec == LAS_PREC_BF16) {
         const int kq = K4p / 32 / 4;                        // k-steps per wave
-        const bool direct = NB <= 2 && NC == 1 && !getenv("LAS_LSTM_NO_DIRECT");
+        const bool direct = NB <= 2 && NC == 1 && !LAS_AB_KNOB("LAS_LSTM_NO_DIRECT");
         if (direct && kq == 8)  { LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_BWD_ARGS))); }
         if (direct && kq == 10) { LAS_NB_SWITCH(NB, return (launch_bwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 10>(LAS_BWD_ARGS))); }
         if (direct && kq == 16 && NB == 1) { return launch_bwd<LAS_PREC_BF16, 1, 16>(LAS_BWD_ARGS); }

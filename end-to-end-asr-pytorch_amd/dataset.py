@@ -120,8 +120,9 @@ class LibriBuckets(_Buckets):
 
     def get(self, i, idx=None):
         items = self.items[i] if idx is None else [self.items[i][k] for k in idx]
-        if not items:                                       # a bucket smaller than the world: nothing for this rank
-            return np.zeros((0, 1, 1), np.float32), np.zeros((0, 2), np.int64)
+        if not items:                                       # a bucket smaller than the world: nothing for this rank, but
+            D = np.load(os.path.join(self.root, self.items[i][0][0]), mmap_mode='r').shape[-1]   # the feature dim stays the
+            return np.zeros((0, 1, D), np.float32), np.zeros((0, 2), np.int64)                   # data's (it sizes the model)
         xs = [np.load(os.path.join(self.root, f)).astype(np.float32) for f, _, _ in items]
         return _pad_x(xs), _pad_y([l for _, _, l in items])
 

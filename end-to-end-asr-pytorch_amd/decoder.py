@@ -232,7 +232,7 @@ class DecoderFn(torch.autograd.Function):
         direct = all(tg[n] is not None for n in names if n not in ('embed.weight', 'char_trans.weight', 'char_trans.bias'))
         # every parameter offers its gradient buffer: the parameter-only sums over the steps (d conv_w, embedding rows, the
         # reduction of the per-utterance accumulators) leave the main stream, which goes on with d enc / d psi
-        split = direct and tg['embed.weight'] is not None and not os.environ.get('LAS_NO_DEC_SPLIT')
+        split = direct and tg['embed.weight'] is not None
         with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (A + E), 'byte'):      # enc + saved s (loc) / psi (dot)
             check(L_.las_decoder_bwd_parts(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
                                            ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), I(1 if split else 3), cur_stream()),

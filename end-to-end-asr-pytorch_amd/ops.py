@@ -4,6 +4,7 @@ import os
 import torch
 
 from . import _lib
+from . import dist as _ldist
 from ._lib import P, I, Z, F, ptr, check, cur_stream
 
 
@@ -86,9 +87,8 @@ def kernel_timing_summary(records):
 # Weight-gradient GEMMs are off the backward dependency chain, and the persistent LSTM kernels that follow them
 # occupy only ND*ceil(H/16)*slices CUs: run the wgrads on a second HIP stream, accumulating directly into the
 # flat gradient buffer (param.grad views), and join before the optimiser.
-_SIDE = {'enabled': True, 'stream': None, 'stream1': None, 'dirty': False, 'dirty1': False,
-         'inline': bool(os.environ.get('LAS_WGRAD_INLINE'))}
-_BRANCH = {'stream': None, 'enabled': not os.environ.get('LAS_NO_CTC_BRANCH')}
+_SIDE = {'enabled': True, 'stream': None, 'stream1': None, 'dirty': False, 'dirty1': False, 'inline': False}
+_BRANCH = {'stream': None, 'enabled': True}           # (scheduling forms are switched by the set_* functions below: tests, tools/)
 _GRAD_READY = None      # dist.backward_with_overlap: called with an encoder layer's first gradient view once that layer's
                         # (and therefore every later parameter's) gradients have all been enqueued
 
@@ -104,7 +104,12 @@ def set_wgrad_inline(flag):
     _SIDE['inline'] = bool(flag)
 
 
-_ONE_SIDE = bool(os.environ.get('LAS_ONE_SIDE_STREAM'))      # (A/B measurements: all weight-gradient work on one side stream)
+_ONE_SIDE = False      # (tools/: all weight-gradient work on one side stream)
+
+
+def set_ctc_branch(flag):
+    """False: the CTC head + loss run on the main stream instead of beside the attend-and-spell loops."""
+    _BRANCH['enabled'] = bool(flag)
 
 
 def _side_stream(which=0):
@@ -326,7 +331,7 @@ def gemm(A, B, C=None, transA=False, transB=False, alpha=1.0, beta=0.0, bias=Non
     return C
 
 
-USE_BF16_TWINS = not os.environ.get('LAS_NO_BF16_TWINS')      # (tests / A-B measurements switch the bf16 operand twins off)
+USE_BF16_TWINS = True      # (tests / tools switch the bf16 operand twins off by assigning this)
 TWIN_MIN_ELEMS = 1 << 18    # below this an operand is not worth a cast pass: the GEMM converts it while staging
 
 
@@ -550,6 +555,8 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     sync, dgx = sx[:nsync], sx[nsync:]              # (one allocation, the workspace behind the sync words: one zero fill)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
+    if _ldist._ACTIVE['ex'] is not None:        # gradient buckets in flight on RCCL's stream: do they and this launch both fit?
+        _ldist.persistent_launch_guard(L_.las_lstm_resident_wgs(I(prec), I(T), I(B), I(H), I(ND)), dev)
     with _Timed(('lstm_bwd_kernel', 'lstm_bwd_ks_kernel', 'lstm_bwd_gr_kernel')[ksplit], 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
                                   I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
@@ -711,6 +718,11 @@ class JointLossFn(torch.autograd.Function):
             check(L_.las_ce_loss(ptr(att_pred), ptr(y), I(y.shape[1]), ptr(ntok), I(B), I(Lx), I(V), F(1.0 - w),
                                  ptr(rowloss), ptr(att), ptr(datt), cur_stream()), 'las_ce_loss')
         cs = getattr(ctc_pred, '_branch', None) if ctc_pred is not None else None
+        pend, _BRANCH['pending'] = _BRANCH.get('pending'), None
+        if cs is None and pend is not None:
+            # the head GEMM was launched on the branch stream but the tensor lost its `_branch` tag on the way here (a slice,
+            # a cast, a user wrapper): no overlap then, but never a race -- the main stream waits for the branch first
+            join_from(pend)
         ctx.branch = cs
         if ctc_pred is not None:
             def ctc_part():

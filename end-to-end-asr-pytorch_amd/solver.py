@@ -108,6 +108,7 @@ class Trainer(Solver):
         if config.get('clm', {}).get('enable', False):
             raise NotImplementedError('CLM adversarial training is out of scope (SURVEY.md §2.1)')
         self._pending = None
+        self.len_stream = True           # length inference + its D2H on a stream of their own (train_step; tests switch it off)
 
     # ------------------------------------------------------------------------------------------------ data
     def load_data(self):
@@ -155,13 +156,13 @@ class Trainer(Solver):
         run on a stream of their own, the host does not wait for the previous step's tail and enqueues this step's
         kernels while that one still runs -- the step has no host bubble at its start."""
         if x.shape[0] == 0:                                       # a bucket smaller than the world: nothing on this rank,
-            ldist.allreduce_grads(self.asr_model.flat_grads)      # but it still joins the exchange and the (global) update
-            self.asr_opt.step(zero_grad=True)
+            ldist.exchange_without_backward(self.asr_model)       # but it joins the exchange (the SAME collective sequence as
+            self.asr_opt.step(zero_grad=True)                     # its peers' backward issues) and the (global) update
             z = torch.zeros((), device=self.device)
             return z, z, z, None, 0
         if inputs_ready is not None and inputs_ready is not True:
             torch.cuda.current_stream().wait_event(inputs_ready)
-        if inputs_ready is not None and host_lens is None and not os.environ.get('LAS_NO_LEN_STREAM'):
+        if inputs_ready is not None and host_lens is None and self.len_stream:
             ls = ops.length_stream()
             if inputs_ready is not True:
                 ls.wait_event(inputs_ready)

@@ -88,6 +88,7 @@ size_t las_lstm_hx_bytes(int prec, int T, int B, int H, int ND);        /* size 
 size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size of the `dgx` exchange workspace of rec_bwd */
 int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* which kernel rec_bwd runs: 2 lstm_bwd_gr_kernel (reduce-scatter of partial dh in tagged granules), 1 lstm_bwd_ks_kernel (the same behind a flag), 0 lstm_bwd_kernel (all-gather of dgates) */
 int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND);       /* which kernel rec_fwd runs: 1 lstm_fwd_gr_kernel (tagged granules), 0 lstm_fwd_kernel */
+int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND);      /* workgroups rec_fwd / rec_bwd keep resident for the whole launch (one per CU, all must be co-resident); callers that overlap other device work with the recurrence (RCCL collectives: dist.py) use it to decide whether that work finds free CUs */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
                      void* hx, float* gates, float* cs, void* sync, int* status, void* stream);

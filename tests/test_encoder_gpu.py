@@ -124,11 +124,11 @@ def test_infer_lengths_and_transpose(ops):
     assert ops.count_nonzero(y).cpu().tolist() == [3, 2]
 
 
-@pytest.mark.parametrize('env', ['LAS_LSTM_NO_XL', 'LAS_LSTM_NO_PF', 'LAS_LSTM_NO_NT'])
+@pytest.mark.parametrize('env', ['LAS_LSTM_NO_XL', 'LAS_LSTM_NO_GR'])
 def test_lstm_exchange_variants(ops, monkeypatch, env):
-    """The C2 launch geometry (one batch tile, K-split backward) through the paths the default launch does not take on
-    this shape: the cross-XCD sc1 hand-off (no XCD-grouped launch), no prefetch wave, plain stores for the saved
-    activations.  The switches are read at every launch."""
+    """The C2 launch geometry (one batch tile, K-split backward) through the documented fallbacks, which the default launch
+    does not take on this shape: the cross-XCD sc1 hand-off (no XCD-grouped launch) and the flag-protocol kernels instead of the
+    tagged-granule ones.  The switches are read at every launch."""
     monkeypatch.setenv(env, '1')
     test_lstm_shapes_vs_oracle(ops, 23, 24, 16, 320, 'bf16')
     test_lstm_shapes_vs_oracle(ops, 17, 12, 8, 64, 'f32')

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 
 }  // namespace
 
+int las_gemm_big(int transA, int transB, int M, int N, int K, float alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
+                 float beta, float* C, int64_t ldc, const float* bias, int act, void* C16, int64_t ldc16, int cfg, hipStream_t st);
+
 static int gemm_common(int prec, int transA, int transB, int M, int N, int K, float alpha, const void* A, int a16,
                        int64_t lda, int64_t strideA, const void* B, int b16, int64_t ldb, int64_t strideB, float beta,
                        float* C, int64_t ldc, int64_t strideC, const float* bias, int act, int batch, void* C16,
@@ -245,6 +248,14 @@ static int gemm_common(int prec, int transA, int transB, int M, int N, int K, fl
     LAS_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     LAS_CHECK_ARG(!C16 || ldc16 >= N);
     if (M == 0 || N == 0) return LAS_OK;
+    if (prec == LAS_PREC_BF16 && a16 && b16 && batch == 1) {
+        // both operands are bf16 twins: the large-tile LDS-DMA kernel (gemm_big.hip) where the shape fills the chip with it
+        static const char* knob = LAS_AB_KNOB("LAS_GEMM_BIG");          // (diagnostic build: 1 | 2 force a tile, -1 = never)
+        const int cfg = knob ? atoi(knob) : 0;
+        const int rc = cfg < 0 ? LAS_E_UNSUPPORTED
+                               : las_gemm_big(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, act, C16, ldc16, cfg, (hipStream_t)stream);
+        if (rc != LAS_E_UNSUPPORTED) return rc;
+    }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     if (grid.y > 65535 || grid.z > 65535) return LAS_E_UNSUPPORTED;
     // split-K for the weight-gradient shapes (few output tiles, K = T*B in the tens of thousands)

@@ -107,3 +107,42 @@ def test_gemm_bf16_sources_equal_converted_fp32_sources(ta, tb, M, N, K):
     g2 = ops.gemm(A, B, C0.clone(), transA=ta, transB=tb, beta=1.0, A16=A16, B16=B16)
     torch.cuda.synchronize()
     assert float((g2 - r2).abs().max()) <= 2e-5 * float(r2.abs().max())     # (split-K partials are added with float atomics)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# gemm_big.hip: the large-tile LDS-DMA kernel las_gemm_ex dispatches to when both operands are bf16 twins and the shape
+# fills the chip.  Shapes chosen so that the dispatcher takes each configuration: 256x256 tiles (16 x 16 = 256 tiles),
+# 256x128 tiles with ragged edges in M and N and a K tail (K % 64 != 0), and the split-K form (few output tiles, long K:
+# the weight-gradient shape).  Reference: fp64 product of the SAME bf16 values -> only the fp32 accumulation order differs.
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K,epi', [(4096, 4096, 512, True), (3608, 4104, 456, True), (512, 640, 16384, False),
+                                       (7200, 2560, 1280, True), (264, 136, 264, True)])
+def test_gemm_big_tile(ops, ta, tb, M, N, K, epi):
+    dev = 'cuda:0'
+    g = torch.Generator(device='cpu').manual_seed(M + 3 * N + 7 * K + 2 * ta + tb)
+    A16 = torch.randn((K, M) if ta else (M, K), generator=g).to(torch.bfloat16)
+    B16 = torch.randn((N, K) if tb else (K, N), generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    opA = (A16.t() if ta else A16).double()
+    opB = (B16.t() if tb else B16).double()
+    prod = opA @ opB
+    ops.set_precision('bf16')
+    Ad, Bd = A16.to(dev), B16.to(dev)
+    Af, Bf = Ad.float(), Bd.float()
+    if epi:      # alpha, beta, bias, tanh and the bf16 copy of the result
+        C = C0.to(dev)
+        C16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        got = ops.gemm(Af, Bf, C, transA=ta, transB=tb, alpha=0.125, beta=1.0, bias=bias.to(dev), act=1, A16=Ad, B16=Bd, C16=C16)
+        torch.cuda.synchronize()
+        want = torch.tanh(0.125 * prod + C0.double() + bias.double())
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * max(1.0, K ** 0.5 / 8), err
+        assert torch.equal(C16, got.to(torch.bfloat16))
+    else:        # accumulate form (the weight gradients): beta = 1, no bias / activation -> split-K eligible
+        C = C0.to(dev)
+        got = ops.gemm(Af, Bf, C, transA=ta, transB=tb, beta=1.0, A16=Ad, B16=Bd)
+        torch.cuda.synchronize()
+        want = prod + C0.double()
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= 3e-6 * float(want.abs().max()) * max(1.0, K ** 0.5 / 32), (err, float(want.abs().max()))

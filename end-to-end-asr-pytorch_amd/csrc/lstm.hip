@@ -193,6 +193,7 @@ struct LstmArgs {
     int nt;                   // forward: non-temporal stores for the saved activations (C2 step -0.2 ms; the same for the
                               // backward kernel's dgf measured neutral)
     int pf;                   // forward: a fifth wave prefetches the x-projection rows into the L2 two steps ahead
+    int pdelay;               // (diagnostic build) granule kernels: units of 64 cycles to sleep before a step's first poll
 };
 
 // Which (direction d, unit slice g, batch slice bs) a workgroup works on.  A GROUP = the G workgroups of one
@@ -526,7 +527,7 @@ __device__ __forceinline__ u32x4 gr_poll(__amdgpu_buffer_rsrc_t rs, int off) {
 constexpr int GR_XLD = 16 * 4 + 4;        // floats per batch row of the x-projection / gate tiles in LDS: [16 units][4 gates] + pad
 constexpr int GR_HLD = 16 * 2 + 2;        // ... of the {h, c} tile
 
-template <int NB, int KS>
+template <int NB, int KS, int SWM = 4>     // SWM: 16-byte granules a lane sweeps per step (4: per-lane lists in registers; more: lists in LDS)
 __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
     float* Sh = Sg + 2 * NB * 16 * GR_XLD;              // [2][NB*16][GR_HLD]  {h, c}
     int* lensl = (int*)(Sh + 2 * NB * 16 * GR_HLD);     // [NB*16]
     int* flag = lensl + NB * 16;
+    int* tab = flag + 4;                                // SWM > 4: [NT][SWM][2] sweep lists (ring offset, h-tile destination)
     const bool io = threadIdx.x >= NT;                  // the fifth wave
     if (!io) {
         for (int i = threadIdx.x; i < NB * 16 * ld; i += NT) ((unsigned*)Hl)[i] = 0u;      // 2 tiles of bf16 = NB*16*ld words
@@ -676,19 +678,21 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
     // my share of the sweep: the workgroup's H * nckl granules in four contiguous quarters, one per wave (equal work, and a
     // wave instruction reads consecutive granules); slot u of lane l is granule wave * Q + 64 u + l.  Offsets in the ring
     // slot, destinations in the h tile and the spare-row flags are the same every step.
-    constexpr int SWMAX = 4;                             // host side: H * chunks(Bs) <= 4 * 256
+    constexpr int SWMAX = SWM;                           // host side: H * chunks(Bs) <= SWM * 256
+    constexpr bool TAB = SWM > 4;                        // (H = 1024: 128 registers hold the weight fragments; the lists live in LDS)
     const int Q = (total + 3) / 4;
     const int nsw = (Q + 63) / 64;
-    int g_off[SWMAX], g_dst[SWMAX];
-    bool g_six[SWMAX];
+    int g_off[TAB ? 1 : SWMAX], g_dst[TAB ? 1 : SWMAX];  // g_dst: (destination << 1) | six-row flag, or -1
+    int* tabw = tab + (int)threadIdx.x * SWMAX * 2;
 #pragma unroll
     for (int u = 0; u < SWMAX; ++u) {
         const int idx = lane + 64 * u, i = wave * Q + idx;
         const bool ok = idx < Q && i < total;
         const int j = ok ? i / nckl : 0, ch = ok ? i - j * nckl : 0, bt = ch / 3, c3 = ch - bt * 3;
-        g_off[u] = ok ? (j * nck + ch) * 16 : 0x7ffffff0;
-        g_dst[u] = ok ? (bt * 16 + c3 * 6) * ld + j : -1;
-        g_six[u] = c3 < 2;
+        const int o_ = ok ? (j * nck + ch) * 16 : 0x7ffffff0;
+        const int d_ = ok ? ((((bt * 16 + c3 * 6) * ld + j) << 1) | (c3 < 2 ? 1 : 0)) : -1;
+        if constexpr (TAB) { tabw[2 * u] = o_; tabw[2 * u + 1] = d_; }
+        else { g_off[u] = o_; g_dst[u] = d_; }
     }
 
     GR_ST_DECL;
@@ -703,12 +707,12 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
             auto sweep = [&](auto swc) -> bool {
                 constexpr int SW = decltype(swc)::value;
                 constexpr int OOB = 0x7ffffff0;
-                u32x4 v[SW], got[SW];
+                u32x4 v[SW], got[TAB ? 1 : SW];
                 int off[SW];
+                for (int dl = 0; dl < a.pdelay; ++dl) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
-                    off[u] = g_off[u];
-                    got[u] = (u32x4){0u, 0u, 0u, 0u};
+                    if constexpr (TAB) off[u] = tabw[2 * u]; else { off[u] = g_off[u]; got[u] = (u32x4){0u, 0u, 0u, 0u}; }
                     v[u] = gr_poll(rs, off[u]);
                 }
                 unsigned spins = 0;
@@ -718,8 +722,18 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                     for (int u = 0; u < SW; ++u) {
                         const bool hit = off[u] != OOB && v[u][3] == (unsigned)s;
                         off[u] = hit ? OOB : off[u];
+                        if constexpr (TAB) {
+                            if (hit) {                   // (lists in LDS: no registers to park the payload in; the loop runs once in steady state)
+                                const int d2 = tabw[2 * u + 1];
+                                bf16_t* dst = buf + (d2 >> 1);
+                                dst[0] = (bf16_t)(v[u][0] & 0xffffu); dst[ld] = (bf16_t)(v[u][0] >> 16);
+                                dst[2 * ld] = (bf16_t)(v[u][1] & 0xffffu); dst[3 * ld] = (bf16_t)(v[u][1] >> 16);
+                                if (d2 & 1) { dst[4 * ld] = (bf16_t)(v[u][2] & 0xffffu); dst[5 * ld] = (bf16_t)(v[u][2] >> 16); }
+                            }
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 3; ++e) got[u][e] = hit ? v[u][e] : got[u][e];
+                            for (int e = 0; e < 3; ++e) got[u][e] = hit ? v[u][e] : got[u][e];
+                        }
                         need = need || off[u] != OOB;
                     }
 #ifdef LAS_PK_STAMPS
@@ -738,16 +752,20 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                 }
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
-                    if (g_dst[u] < 0) continue;
-                    bf16_t* dst = buf + g_dst[u];
+                    if constexpr (TAB) continue;
+                    const int d2 = g_dst[u];
+                    if (d2 < 0) continue;
+                    bf16_t* dst = buf + (d2 >> 1);
                     dst[0] = (bf16_t)(got[u][0] & 0xffffu); dst[ld] = (bf16_t)(got[u][0] >> 16);
                     dst[2 * ld] = (bf16_t)(got[u][1] & 0xffffu); dst[3 * ld] = (bf16_t)(got[u][1] >> 16);
-                    if (g_six[u]) { dst[4 * ld] = (bf16_t)(got[u][2] & 0xffffu); dst[5 * ld] = (bf16_t)(got[u][2] >> 16); }
+                    if (d2 & 1) { dst[4 * ld] = (bf16_t)(got[u][2] & 0xffffu); dst[5 * ld] = (bf16_t)(got[u][2] >> 16); }
                 }
                 return true;
             };
-            const bool ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
-                           : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            bool ok_;
+            if constexpr (SWM > 4) ok_ = nsw <= 6 ? sweep(std::integral_constant<int, 6>{}) : sweep(std::integral_constant<int, SWM>{});
+            else ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
+                     : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
             if (!ok_) return;
         }
         GR_ST(0);
@@ -762,6 +780,28 @@ GR_ST(1);
             acc2[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (s > 0) {
+            if constexpr (KS > 16) {
+                // 128 registers hold the weights: the h fragments come in chunks of 4 k-steps, the NEXT chunk requested before
+                // the current one's MFMAs (one chunk = 4 LDS reads per lane; without the overlap every chunk waited out the
+                // LDS latency: 1 900 cycles per step for 32 MFMAs)
+                constexpr int CH = 4, NCH = KS / CH;
+                bf16x8 hc[2][CH];
+#pragma unroll
+                for (int ks = 0; ks < CH; ++ks) hc[0][ks] = *(const bf16x8*)(buf + fr * ld + min(ks * 32, Kp - 32) + fq * 8);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) {
+#pragma unroll
+                        for (int ks = 0; ks < CH; ++ks)
+                            hc[(c + 1) & 1][ks] = *(const bf16x8*)(buf + fr * ld + min(((c + 1) * CH + ks) * 32, Kp - 32) + fq * 8);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < CH; ++ks) {
+                        if (ks & 1) acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[c * CH + ks], hc[c & 1][ks], acc2[0], 0, 0, 0);
+                        else acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[c * CH + ks], hc[c & 1][ks], acc[0], 0, 0, 0);
+                    }
+                }
+            } else {
             constexpr int CH = KS <= 10 ? KS : 8;
 #pragma unroll
             for (int k0 = 0; k0 < KS; k0 += CH) {
@@ -779,6 +819,7 @@ GR_ST(1);
                         if (ks & 1) acc2[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[k0 + ks], hv_[ks][bt], acc2[bt], 0, 0, 0);
                         else acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[k0 + ks], hv_[ks][bt], acc[bt], 0, 0, 0);
                     }
+            }
             }
         }
 #ifdef LAS_PK_STAMPS
@@ -1253,7 +1294,7 @@ __global__ __launch_bounds__(NT) void lstm_bwd_ks_kernel(LstmArgs a, const float
 // dgates tile complete).  The compute waves touch global memory only for the hand-off: a fifth wave loads gates / c /
 // c_prev / dy three steps ahead into LDS and stores d gates (the weight-gradient GEMMs' operand) from LDS.
 constexpr int BG_CLD = 16 * 4 + 4;                       // floats per batch row of the {c, c_prev, dy, -} tile
-template <int NB, int MT>
+template <int NB, int MT, int SWM = 4>
 __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const float* __restrict__ dy,
                                                          const float* __restrict__ gates, const float* __restrict__ cs,
                                                          const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -1275,6 +1316,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
     float* Do = Ci + 2 * NB * 16 * BG_CLD;                // [2][NB*16][GR_XLD]  d gates in f32            (compute -> I/O wave)
     int* lensl = (int*)(Do + 2 * NB * 16 * GR_XLD);
     int* flag = lensl + NB * 16;
+    int* tab = flag + 4;                                  // SWM > 4: [NT][SWM][2] sweep lists
     const bool io = threadIdx.x >= NT;
     if (!io) {
         for (int i = threadIdx.x; i < NB * 16 * LDK / 2; i += NT) ((unsigned*)Dl)[i] = 0u;
@@ -1402,16 +1444,20 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
     const long slot_stride = (long)ND * a.NS * G * G * RW;
     u32x4* ringg = ring + ((long)d * a.NS + bs) * G * G * RW;
     // my share of the sweep (see lstm_fwd_gr_kernel): granule i = (producer p, row, column group cg)
-    constexpr int SWMAX = 4;
+    constexpr int SWMAX = SWM;
+    constexpr bool TAB = SWM > 4;
     const int total = G * Bl * 4, Q = (total + 3) / 4, nsw = (Q + 63) / 64;
-    int g_off[SWMAX], g_dst[SWMAX];
+    int g_off[TAB ? 1 : SWMAX], g_dst[TAB ? 1 : SWMAX];
+    int* tabw = tab + (int)threadIdx.x * SWMAX * 2;
 #pragma unroll
     for (int u = 0; u < SWMAX; ++u) {
         const int idx = lane + 64 * u, i = wave * Q + idx;
         const bool ok = idx < Q && i < total;
         const int p = ok ? i / (Bl * 4) : 0, rem = ok ? i - p * (Bl * 4) : 0, row = rem >> 2, cg = rem & 3;
-        g_off[u] = ok ? ((g * G + p) * RW + rem) * 16 : OOB;
-        g_dst[u] = ok ? row * RLD + cg * 4 * PS + p : -1;
+        const int o_ = ok ? ((g * G + p) * RW + rem) * 16 : OOB;
+        const int d_ = ok ? row * RLD + cg * 4 * PS + p : -1;
+        if constexpr (TAB) { tabw[2 * u] = o_; tabw[2 * u + 1] = d_; }
+        else { g_off[u] = o_; g_dst[u] = d_; }
     }
 
     // The part of the cell backward that does not depend on dh_{rec} is taken BEFORE the sweep, from inputs the I/O wave
@@ -1448,12 +1494,12 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
             auto sweep = [&](auto swc) -> bool {
                 constexpr int SW = decltype(swc)::value;
                 u32x4 v[SW];
-                unsigned got[SW][2];
+                unsigned got[TAB ? 1 : SW][2];
                 int off[SW];
+                for (int dl = 0; dl < a.pdelay; ++dl) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
-                    off[u] = g_off[u];
-                    got[u][0] = got[u][1] = 0u;
+                    if constexpr (TAB) off[u] = tabw[2 * u]; else { off[u] = g_off[u]; got[u][0] = got[u][1] = 0u; }
                     v[u] = gr_poll(rs, off[u]);
                 }
                 precompute(s);                           // (its inputs were delivered before B(s-1)): under the first poll's round trip
@@ -1464,8 +1510,16 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                     for (int u = 0; u < SW; ++u) {
                         const bool hit = off[u] != OOB && v[u][2] == (unsigned)s;
                         off[u] = hit ? OOB : off[u];
-                        got[u][0] = hit ? v[u][0] : got[u][0];
-                        got[u][1] = hit ? v[u][1] : got[u][1];
+                        if constexpr (TAB) {
+                            if (hit) {
+                                float* dst = Red + tabw[2 * u + 1];
+                                dst[0] = __uint_as_float(v[u][0] << 16); dst[PS] = __uint_as_float(v[u][0] & 0xffff0000u);
+                                dst[2 * PS] = __uint_as_float(v[u][1] << 16); dst[3 * PS] = __uint_as_float(v[u][1] & 0xffff0000u);
+                            }
+                        } else {
+                            got[u][0] = hit ? v[u][0] : got[u][0];
+                            got[u][1] = hit ? v[u][1] : got[u][1];
+                        }
                         need = need || off[u] != OOB;
                     }
 #ifdef LAS_PK_STAMPS
@@ -1484,15 +1538,20 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                 }
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
-                    if (g_dst[u] < 0) continue;
-                    float* dst = Red + g_dst[u];
+                    if constexpr (TAB) continue;
+                    const int d2 = g_dst[u];
+                    if (d2 < 0) continue;
+                    float* dst = Red + d2;
                     dst[0] = __uint_as_float(got[u][0] << 16); dst[PS] = __uint_as_float(got[u][0] & 0xffff0000u);
                     dst[2 * PS] = __uint_as_float(got[u][1] << 16); dst[3 * PS] = __uint_as_float(got[u][1] & 0xffff0000u);
                 }
                 return true;
             };
-            const bool ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
-                           : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
+            bool ok_;
+            if constexpr (SWM > 4) ok_ = nsw <= 6 ? sweep(std::integral_constant<int, 6>{})
+                                       : nsw <= 9 ? sweep(std::integral_constant<int, 9>{}) : sweep(std::integral_constant<int, SWM>{});
+            else ok_ = nsw <= 2 ? sweep(std::integral_constant<int, 2>{})
+                     : nsw == 3 ? sweep(std::integral_constant<int, 3>{}) : sweep(std::integral_constant<int, 4>{});
             if (!ok_) return;
         }
         GR_ST(0);
@@ -1565,8 +1624,9 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
     GR_ST_PRINT(a.T);
 }
 size_t bwd_gr_lds(int H, int NB) {
-    const int G = (H + 15) / 16, PS = (G + 3) / 4 <= 5 ? 20 : 32, RLD = 16 * PS + 4;
-    return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4);
+    const int G = (H + 15) / 16, mt = (G + 3) / 4, PS = mt <= 5 ? 20 : mt <= 8 ? 32 : 64, RLD = 16 * PS + 4;
+    return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4) +
+           (mt > 8 ? sizeof(int) * NT * 12 * 2 : 0);
 }
 size_t bwd_gr_ring_bytes(const LstmArgs& a) { return (size_t)16 * KS_SLOTS * a.ND * a.NS * a.G * a.G * a.Bs * 4; }
 
@@ -1631,6 +1691,8 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     a.nt = no_nt ? 0 : 1;
     const bool no_pf = LAS_AB_KNOB("LAS_LSTM_NO_PF") != nullptr;
     a.pf = no_pf ? 0 : 1;
+    const char* pd = LAS_AB_KNOB("LAS_LSTM_POLL_DELAY");
+    a.pdelay = pd ? atoi(pd) : 0;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
 
@@ -1646,18 +1708,19 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
     LAS_LAUNCH_OK();
     return LAS_OK;
 }
-size_t fwd_gr_lds(int H, int NB) {
+size_t fwd_gr_lds(int H, int NB, int swm = 4) {
     const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
-    return (size_t)2 * NB * 16 * ld * 2 + sizeof(float) * 2 * NB * 16 * (2 * GR_XLD + GR_HLD) + sizeof(int) * (NB * 16 + 4);
+    return (size_t)2 * NB * 16 * ld * 2 + sizeof(float) * 2 * NB * 16 * (2 * GR_XLD + GR_HLD) + sizeof(int) * (NB * 16 + 4) +
+           (swm > 4 ? sizeof(int) * NT * swm * 2 : 0);
 }
 size_t fwd_gr_ring_bytes(const LstmArgs& a) {
     return (size_t)16 * a.ND * HX_SLOTS * a.NS * a.H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6);
 }
-template <int NB, int KS>
+template <int NB, int KS, int SWM = 4>
 int launch_fwd_gr(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
                   const float* w_hh, const int32_t* lens, float* y, float* hf, void* hx, float* gates, float* cs,
                   SyncWords* sync, int* status) {
-    auto k = lstm_fwd_gr_kernel<NB, KS>;
+    auto k = lstm_fwd_gr_kernel<NB, KS, SWM>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if ((char*)hx != (char*)sync + sizeof(SyncWords))                    // (else: zeroed together with the sync words by the caller below)
         LAS_HIP(hipMemsetAsync(hx, 0, fwd_gr_ring_bytes(a), st));      // tags of earlier launches must not match
@@ -1693,7 +1756,10 @@ int bwd_plan(int prec, int T, int B, int H, int ND, const LstmArgs& a, BwdPlan& 
         else if (prec == LAS_PREC_BF16 && mt <= 16 && bwd_ks_lds(prec, H, p.NB, true) <= LDS_CAP) p.ks = p.wdirect = true;
     }
     // tagged-granule hand-off (lstm_bwd_gr_kernel): bf16, <= 8 consumers per wave, <= 1 024 granules per inbox and step
-    p.gr = p.ks && prec == LAS_PREC_BF16 && (a.G + 3) / 4 <= 8 && H % 4 == 0 && (long)a.G * a.Bs * 4 <= 1024 &&
+    // (more than 32 producers -- 512 < H <= 1024 --: one batch tile per slice, up to 12 granules per lane and step, lists in LDS)
+    const int mt_ = (a.G + 3) / 4;
+    p.gr = p.ks && prec == LAS_PREC_BF16 && (mt_ <= 8 || (mt_ <= 16 && p.NB == 1)) && H % 4 == 0 &&
+           (long)a.G * a.Bs * 4 <= (mt_ > 8 ? 3072 : 1024) &&
            (long)T * B * ND * 4 * H * 4 < (1l << 31) && bwd_gr_lds(H, p.NB) <= LDS_CAP && !las_fallback("LAS_LSTM_NO_GR");
     if (p.gr) {
         p.wdirect = false;
@@ -1764,8 +1830,11 @@ extern "C" int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND) {
 
 // 1: lstm_fwd_gr_kernel (tagged-granule hand-off), 0: lstm_fwd_kernel.  Same rule as in las_lstm_rec_fwd below.
 static bool fwd_uses_gr(int prec, int T, int B, int H, int ND, const LstmArgs& a, int U, int NB, int KS) {
-    return prec == LAS_PREC_BF16 && KS > 0 && KS <= 16 && U == 16 && H % 4 == 0 && (long)T * B * ND * 4 * H * 4 < (1l << 31) &&
-           (long)H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6) <= 1024 && !las_fallback("LAS_LSTM_NO_GR");
+    // KS = 32 (512 < H <= 1024, one batch tile per slice): the weight fragments take 128 registers per lane, the sweep lists
+    // move to LDS and a lane sweeps up to 8 granules per step
+    const bool big = KS == 32 && NB == 1;
+    return prec == LAS_PREC_BF16 && KS > 0 && (KS <= 16 || big) && U == 16 && H % 4 == 0 && (long)T * B * ND * 4 * H * 4 < (1l << 31) &&
+           (long)H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6) <= (big ? 2048 : 1024) && !las_fallback("LAS_LSTM_NO_GR");
 }
 extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
@@ -1775,6 +1844,7 @@ extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
     int KS = 0;
     if (prec == LAS_PREC_BF16 && NB >= 1 && NB <= 2 && !LAS_AB_KNOB("LAS_LSTM_NO_DIRECT"))
         KS = ksteps <= 8 ? 8 : ksteps <= 10 ? 10 : (ksteps <= 16 && NB == 1) ? 16 : 0;
+    if (prec == LAS_PREC_BF16 && NB >= 1 && NB <= 2 && KS == 0 && ksteps <= 32 && fwd_lds(prec, H, NB, false) > LDS_CAP) KS = 32;     // (as las_lstm_rec_fwd)
     const bool u8 = !a.xl && ND * ((H + 7) / 8) <= las_cu_count() && H == 512;
     return fwd_uses_gr(prec, T, B, H, ND, a, u8 ? 8 : 16, NB, KS) ? 1 : 0;
 }
@@ -1824,7 +1894,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
         if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
         if (KS == 10) { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
         if (KS == 16) { return launch_fwd_gr<1, 16>(LAS_FWD_ARGS); }
-        // (KS = 32, H > 512: 128 registers of weight fragments per lane leave no room for a fifth wave on the CU)
+        if (KS == 32) { lds = fwd_gr_lds(H, 1, 8); return launch_fwd_gr<1, 32, 8>(LAS_FWD_ARGS); }
     }
     if (prec == LAS_PREC_BF16) {
         if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd<LAS_PREC_BF16, NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
@@ -1861,7 +1931,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
         if (!ring_behind) LAS_HIP(hipMemsetAsync(dgx, 0, p.ws, st));      // tags of earlier launches must not match
 #define LAS_GR_GO(N_, M_)                                                                                              \
     {                                                                                                                 \
-        auto k = lstm_bwd_gr_kernel<N_, M_>;                                                                          \
+        auto k = lstm_bwd_gr_kernel<N_, M_, (M_ > 8 ? 12 : 4)>;                                                                          \
         LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(NT + 64), lds, st, a, dy, gates, cs, w_hh, lens, (u32x4*)dgx, dgf, \
                            (SyncWords*)sync, status);                                                                 \
@@ -1869,7 +1939,7 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
         return LAS_OK;                                                                                                \
     }
         const int mt = (a.G + 3) / 4;
-        if (NB == 1) { if (mt <= 5) LAS_GR_GO(1, 5) else LAS_GR_GO(1, 8) }
+        if (NB == 1) { if (mt <= 5) LAS_GR_GO(1, 5) else if (mt <= 8) LAS_GR_GO(1, 8) else LAS_GR_GO(1, 16) }
         else { if (mt <= 5) LAS_GR_GO(2, 5) else LAS_GR_GO(2, 8) }
 #undef LAS_GR_GO
     }

@@ -10,7 +10,10 @@ ops.set_precision('bf16')
 import os
 T = int(os.environ.get("T", 300))
 SR = int(os.environ.get("SR", 1))
-for (B, H, ND) in [(24, 320, 2), (12, 320, 2), (12, 320, 1), (24, 160, 2), (12, 160, 2), (12, 64, 2), (12, 32, 1), (12, 16, 1), (48, 320, 2), (24, 512, 2)]:
+SHAPES = [(24, 320, 2), (12, 320, 2), (12, 320, 1), (24, 160, 2), (12, 160, 2), (12, 64, 2), (12, 32, 1), (12, 16, 1), (48, 320, 2), (24, 512, 2), (24, 1024, 2), (12, 1024, 2), (24, 768, 2)]
+if os.environ.get('ONLY_H'):
+    SHAPES = [s_ for s_ in SHAPES if s_[1] == int(os.environ['ONLY_H'])]
+for (B, H, ND) in SHAPES:
     I = 64
     x = torch.randn(T, B, I, device=dev, requires_grad=True)
     lens = torch.full((B,), T, dtype=torch.int32, device=dev)

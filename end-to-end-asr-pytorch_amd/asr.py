@@ -249,12 +249,16 @@ class Seq2Seq(nn.Module):
         return beam_decode(self, audio_feature, decode_step, state_len, decode_beam_size)
 
     # -- full forward ----------------------------------------------------------------------------------------
-    def forward(self, audio_feature, decode_step, tf_rate=0.0, teacher=None, state_len=None, state_len_dev=None):
+    def forward(self, audio_feature, decode_step, tf_rate=0.0, teacher=None, state_len=None, state_len_dev=None, replay=None):
         """reference asr.py:58-112.  Returns (ctc_output [B,T',V]|None, encode_len list[int],
         att_output [B,L,V]|None, att_maps [ (B,L,T') ]|None).
         state_len_dev (not in the reference): the int32 device copy of a host list `state_len` when the caller has both
         (Trainer.train_step) -- building it here from the list is a pageable H2D copy, which makes the host wait for
-        everything queued on the stream, i.e. for the whole previous step."""
+        everything queued on the stream, i.e. for the whole previous step.
+        replay (not in the reference; tests): dict(flips=[bool] * decode_step[, tokens={t: LongTensor[B]}]) -- the recorded
+        coin flips of asr.py:96 instead of fresh ones and, for the steps whose flip said "sample", the recorded draws of
+        asr.py:99 instead of the device sampler's.  A step fed a recorded draw is a teacher-forced step on that token
+        (the draw is not differentiated through), which is how it is run."""
         x = audio_feature
         if not x.is_cuda:
             raise ops._lib.LasError('Seq2Seq.forward needs HIP device tensors (no CPU path)')
@@ -294,10 +298,18 @@ class Seq2Seq(nn.Module):
             # one coin flip per step for the whole batch (asr.py:96); the flip after step t picks step t+1's input
             if teacher is not None:
                 flips = [random.random() <= tf_rate for _ in range(L)]
+                if replay is not None:
+                    flips = [bool(v) for v in replay['flips']][:L]
                 mode = [1] + [1 if f else 0 for f in flips[:L - 1]]
                 y = teacher.to(device=x.device, dtype=torch.int64).contiguous()
                 if y.shape[1] < L:
                     raise ValueError('teacher shorter than decode_step')
+                if replay is not None and replay.get('tokens'):
+                    y = y.clone()
+                    for t, tok in replay['tokens'].items():      # the draw after step t feeds step t + 1
+                        if t + 1 < L:
+                            y[:, t + 1] = torch.as_tensor(tok).to(device=x.device, dtype=torch.int64)
+                            mode[t + 1] = 1
             else:
                 mode = [1] + [2] * (L - 1)
                 y = None

@@ -412,6 +412,16 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
     return LAS_OK;
 }
 
+// The token draw of a scheduled-sampling / greedy step on its own (reference asr.py:99 Categorical(softmax).sample(), :102 argmax):
+// the kernel las_decoder_fwd launches per sampled step, exposed so that its distribution can be tested.
+extern "C" int las_sample_rows(const float* logits, int rows, int V, int greedy, unsigned seed, int32_t* tok, void* stream) {
+    LAS_CHECK_ARG(logits && tok && rows >= 0 && V > 0);
+    if (rows == 0) return LAS_OK;
+    hipLaunchKernelGGL(pick_token_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, V, greedy ? 1 : 0, seed, tok);
+    LAS_LAUNCH_OK();
+    return LAS_OK;
+}
+
 extern "C" int las_decoder_fwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
                                const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode,
                                unsigned seed, las_dec_state* st_, void* stream) {

@@ -125,7 +125,7 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
     if step_mode is not None:
         sm = (ctypes.c_uint8 * L)(*[int(v) for v in step_mode])
     # algorithmic HBM bytes of the attention steps: psi + enc re-read per step
-    with ops._Timed('decoder_fwd (L attend+spell steps)', 4.0 * L * B * Tp * (A + E), 'byte'):
+    with ops._Timed('decoder_fwd (L attend+spell steps)', (2.0 if ops._prec == 0 else 4.0) * L * B * Tp * (A + E), 'byte'):
         check(L_.las_decoder_fwd(ctypes.byref(dims), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
                                  ptr(y) if y is not None else None, I(y.shape[1] if y is not None else 0), sm,
                                  ctypes.c_uint(seed & 0xffffffff), ctypes.byref(st), cur_stream()), 'las_decoder_fwd')
@@ -167,6 +167,7 @@ class DecoderFn(torch.autograd.Function):
       -> h_top [L,B,C] (time-major top-layer states), att [L,B,T'] (non-differentiable)."""
 
     persistent_bwd = True       # (tests switch it off to compare against the per-step BPTT kernels)
+    last_tok = None
 
     @staticmethod
     def forward(ctx, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, *weights):
@@ -181,6 +182,7 @@ class DecoderFn(torch.autograd.Function):
             seed, dropout, drop_seed = seed
         S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, dropout, drop_seed, status=status)
         ctx.S, ctx.W, ctx.cfg = S, W, (L, NL, loc, names)
+        DecoderFn.last_tok = S['tok']                     # int32 [L][B]: the token fed at every step (tests read the sampler's draws)
         ctx.save_for_backward(enc, psi, enc_len)
         h_top = S['hs'][NL - 1, 1:]
         att = S['att'][1:]
@@ -233,7 +235,7 @@ class DecoderFn(torch.autograd.Function):
         # every parameter offers its gradient buffer: the parameter-only sums over the steps (d conv_w, embedding rows, the
         # reduction of the per-utterance accumulators) leave the main stream, which goes on with d enc / d psi
         split = direct and tg['embed.weight'] is not None
-        with ops._Timed('decoder_bwd (L steps BPTT)', 4.0 * L * B * Tp * (A + E), 'byte'):      # enc + saved s (loc) / psi (dot)
+        with ops._Timed('decoder_bwd (L steps BPTT)', (2.0 if ops._prec == 0 else 4.0) * L * B * Tp * (A + E), 'byte'):      # enc + saved s (loc) / psi (dot)
             check(L_.las_decoder_bwd_parts(ctypes.byref(d), ctypes.byref(params), ptr(enc), ptr(psi), ptr(enc_len),
                                            ctypes.byref(st), ptr(g_htop), ctypes.byref(bw), I(1 if split else 3), cur_stream()),
                   'las_decoder_bwd_parts')

@@ -183,6 +183,11 @@ int las_decoder_fwd(const las_dec_dims* dims, const las_dec_params* params, cons
                     const int32_t* enc_len, const int64_t* y, int Ly, const uint8_t* step_mode, unsigned seed,
                     las_dec_state* state, void* stream);
 
+/* tok[r] = a draw from softmax(logits[r][:]) (greedy == 0; counter-hash Gumbel-max: same distribution as
+ * `Categorical(F.softmax(cur_char)).sample()`, src/asr.py:99, not the same stream) or argmax (greedy != 0, src/asr.py:102):
+ * the token choice las_decoder_fwd makes between two steps, with seed = its seed + 0x9e3779b9 * step. */
+int las_sample_rows(const float* logits, int rows, int V, int greedy, unsigned seed, int32_t* tok, void* stream);
+
 typedef struct {                    /* backward buffers (caller-owned); the driver zeroes what it accumulates into */
     float* dgates;                  /* [NL][L][B][4C]  d loss / d gate pre-activations */
     float* dxin;                    /* [L][B][C+E]     d loss / d cell-0 input (embedding | context) */

@@ -202,14 +202,18 @@ def attention_init(enc, lens, W):
     return dict(mask=mask, psi=psi, prev=prev)
 
 
-def attention_step(h, enc, st, W, mode):
-    """asr.py:421-457.  Returns (score (B,T'), context (B,E)); updates st['prev'] in loc mode."""
-    q = torch.tanh(F.linear(h, W['attention.phi.weight']))
+def attention_step(h, enc, st, W, mode, bf16_operands=False):
+    """asr.py:421-457.  Returns (score (B,T'), context (B,E)); updates st['prev'] in loc mode.
+    bf16_operands (checks of the product's bf16 mode only): the operands of the matrix products the HIP path runs on the
+    matrix cores (phi h, W_lp f, the context's enc) are rounded to bf16 (RNE), everything else stays fp32; the cast is the
+    identity for autograd, so the backward pass is the exact derivative of that forward."""
+    r = _rb if bf16_operands else (lambda t_: t_)
+    q = torch.tanh(F.linear(r(h), r(W['attention.phi.weight'])))
     if mode == 'dot':
         e = torch.einsum('bta,ba->bt', st['psi'], q)
     elif mode == 'loc':
         f = F.conv1d(st['prev'].unsqueeze(1), W['attention.loc_conv.weight'], padding=LOC_K)   # (B,C,T')
-        u = torch.tanh(F.linear(f.transpose(1, 2), W['attention.loc_proj.weight']))           # (B,T',A)
+        u = torch.tanh(F.linear(r(f.transpose(1, 2)), r(W['attention.loc_proj.weight'])))     # (B,T',A)
         e = F.linear(torch.tanh(st['psi'] + q.unsqueeze(1) + u),
                      W['attention.gen_energy.weight'], W['attention.gen_energy.bias']).squeeze(2)
     else:
@@ -218,19 +222,20 @@ def attention_step(h, enc, st, W, mode):
     a = torch.softmax(e * ATT_SCALE, dim=-1)
     if mode == 'loc':
         st['prev'] = a
-    ctx = torch.einsum('bt,bte->be', a, enc)
+    ctx = torch.einsum('bt,bte->be', a, r(enc))
     return a, ctx
 
 
 # ----------------------------------------------------------------------------- decoder
-def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    g = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, bf16_operands=False):
+    r = _rb if bf16_operands else (lambda t_: t_)
+    g = F.linear(r(x), r(w_ih), b_ih) + F.linear(r(h), r(w_hh), b_hh)
     i, f, gg, o = g.chunk(4, dim=-1)
     c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
     return torch.sigmoid(o) * torch.tanh(c), c
 
 
-def speller_step(inp, hs, cs, W, n_layers, masks=None):
+def speller_step(inp, hs, cs, W, n_layers, masks=None, bf16_operands=False):
     """asr.py:352-357.  masks (dropout replay): masks[0] multiplies the cell-0 input (asr.py:353), masks[l] the
     recurrent state h_l of layer l >= 1 (asr.py:355: dropout sits on the hidden input, not on the layer input); each
     already scaled by 1/(1-p).  None = dropout 0 / eval."""
@@ -238,17 +243,18 @@ def speller_step(inp, hs, cs, W, n_layers, masks=None):
     if masks is not None:
         inp = inp * masks[0]
     hs[0], cs[0] = lstm_cell(inp, hs[0], cs[0], W[p + '0.weight_ih'], W[p + '0.weight_hh'],
-                             W[p + '0.bias_ih'], W[p + '0.bias_hh'])
+                             W[p + '0.bias_ih'], W[p + '0.bias_hh'], bf16_operands)
     for l in range(1, n_layers):
         hl = hs[l] * masks[l] if masks is not None else hs[l]
         hs[l], cs[l] = lstm_cell(hs[l - 1], hl, cs[l], W[f'{p}{l}.weight_ih'], W[f'{p}{l}.weight_hh'],
-                                 W[f'{p}{l}.bias_ih'], W[f'{p}{l}.bias_hh'])
+                                 W[f'{p}{l}.bias_ih'], W[f'{p}{l}.bias_hh'], bf16_operands)
     return hs[-1]
 
 
-def seq2seq_forward(W, cfg, x, decode_step, teacher=None, lens=None, fast=False, use_teacher=None):
+def seq2seq_forward(W, cfg, x, decode_step, teacher=None, lens=None, fast=False, use_teacher=None, sampled=None):
     """asr.py:58-112.  `use_teacher[t]` replays the per-step coin flips (asr.py:96); default all True.
-    Without a teacher the argmax is fed back (asr.py:102)."""
+    Without a teacher the argmax is fed back (asr.py:102); `sampled[t]` (LongTensor [B]) replays the token the
+    scheduled-sampling draw of asr.py:99 produced after step t (it is not differentiated through, as in the reference)."""
     enc, enc_len = listener(x, lens, W, cfg, fast)
     B = x.shape[0]
     ctc_out = att_out = att_map = None
@@ -269,6 +275,8 @@ def seq2seq_forward(W, cfg, x, decode_step, teacher=None, lens=None, fast=False,
             cur = F.linear(top, W['char_trans.weight'], W['char_trans.bias'])
             if temb is not None and (use_teacher is None or use_teacher[t]):
                 last = temb[:, t + 1]
+            elif sampled is not None and t in sampled:
+                last = emb[torch.as_tensor(sampled[t]).long()]
             else:
                 last = emb[torch.argmax(cur, dim=-1)]
             logits.append(cur)

@@ -215,3 +215,50 @@ def test_lstm_bf16_forward_tight(ops, T, B, Iin, H, sr):
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     close(y, yr.numpy(), dict(atol=2e-3, rtol=2e-3))
+
+
+@pytest.mark.parametrize('T,B,Iin,H,sr', [(19, 24, 64, 1024, 2), (31, 24, 160, 320, 2), (19, 24, 32, 512, 1)])
+def test_lstm_bf16_backward_tight(ops, T, B, Iin, H, sr):
+    """BPTT of the bf16-mode kernels (H = 320: lstm_bwd_gr_kernel; H = 512 / 1024: its 32- / 64-producer forms) against
+    autograd through the oracle run with the SAME operand rounding in the forward pass (bf16 RNE operands of both matrix
+    products; the cast is the identity for autograd, so the oracle's backward is the exact derivative of that forward).
+    What still differs is the rounding of the BACKWARD operands (d gates and the partial d h exchanged as bf16, the bf16
+    twins of the weight-gradient GEMMs): every gradient within 5e-3 of its tensor's largest entry (measured 3.6e-3 at worst), against the 5e-2 / 8e-2
+    that separate bf16 mode from pure fp32.  A dropped or doubled term (a wrong piece of the K-split sum, a step off in the
+    carried d c) is an error of order 1 / G or more and shows."""
+    from oracle import las_ref as R
+    rng = np.random.RandomState(H + 3 * T)
+    lens = sorted(rng.randint(max(1, T // 2), T + 1, size=B).tolist(), reverse=True); lens[0] = T
+    x = np.zeros((B, T, Iin), np.float32)
+    for b, l in enumerate(lens):
+        x[b, :l] = rng.randn(l, Iin)
+    W = {}
+    for sfx in ['', '_reverse']:
+        W['L.layer.weight_ih_l0' + sfx] = torch.tensor((rng.randn(4 * H, Iin) / np.sqrt(Iin)).astype(np.float32), requires_grad=True)
+        W['L.layer.weight_hh_l0' + sfx] = torch.tensor((rng.randn(4 * H, H) / np.sqrt(H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_ih_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+        W['L.layer.bias_hh_l0' + sfx] = torch.tensor((0.1 * rng.randn(4 * H)).astype(np.float32), requires_grad=True)
+    xr = torch.tensor(x, requires_grad=True)
+    yr, _ = R.rnn_layer(xr, lens, W, 'L', sr, 'concat', True, bf16_operands=True)
+    gy = rng.randn(*yr.shape).astype(np.float32)
+    (yr * torch.tensor(gy)).sum().backward()
+    dd = {k[len('L.layer.'):]: v.detach().numpy() for k, v in W.items()}
+    gd = {k[len('L.layer.'):]: v.grad.numpy() for k, v in W.items()}
+    w_ih, w_hh, b_ih, b_hh = [T_(v, True) for v in cat_lstm_weights(dd, '', True)]
+    xg = T_(x, True)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.set_precision('bf16')
+    y = ops.Transpose01Fn.apply(ops.lstm_layer(ops.Transpose01Fn.apply(xg), torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                               w_ih, w_hh, b_ih, b_hh, sr, True, status))
+    (y * T_(gy)).sum().backward()
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    close(y, yr.detach().numpy(), dict(atol=2e-3, rtol=2e-3))
+    g_ih, g_hh, g_bi, g_bh = cat_lstm_weights(gd, '', True)
+    worst = {}
+    for name, got, ref in [('d x', xg.grad, xr.grad.numpy()), ('d w_ih', w_ih.grad, g_ih), ('d w_hh', w_hh.grad, g_hh), ('d b', b_ih.grad, g_bi)]:
+        got = got.detach().cpu().numpy().reshape(ref.shape)
+        worst[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
+    print('lstm bf16 backward, worst / largest entry:', H, worst)
+    assert max(worst.values()) <= 5e-3, worst

@@ -246,3 +246,34 @@ def test_beam_decode(name):
     for i, (seq, scores) in enumerate(hyps):
         assert seq == d[f'hyp{i}.seq'].tolist(), (i, seq)
         close(np.array(scores), d[f'hyp{i}.scores'], atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['dot_att', 'loc_ctc'])
+def test_scheduled_sampling_replay(name):
+    """Scheduled sampling (reference asr.py:95-100) at tf_rate 0.5: g9_sched_* hold the values random.random() returned at
+    asr.py:96 and the tokens Categorical.sample() drew at :99 in the reference's own run.  Replaying both through the
+    oracle (teacher input where the flip said so, the recorded draw otherwise) reproduces its logits, attention maps,
+    losses and every (clipped) gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tools'))
+    from gen_golden import TINY
+    d = G(f'g9_sched_{name}.npz')
+    cfg = R.parse_cfg(TINY[name])
+    W = {k: v.requires_grad_(True) for k, v in W_of(d).items()}
+    x, y = torch.tensor(d['x']), torch.tensor(d['y'])
+    flips = [bool(v <= 0.5) for v in d['flip_values']]
+    assert not all(flips) and any(flips)
+    sampled = {int(t): torch.tensor(tok) for t, tok in zip(d['draw_step'], d['draw_tokens'])}
+    assert sorted(sampled) == [t for t, f in enumerate(flips) if not f]
+    L = int((y != 0).sum(-1).max())
+    ctc_pred, enc_len, att_pred, att_map = R.seq2seq_forward(W, cfg, x, L, teacher=y, lens=R.infer_lengths(x), use_teacher=flips,
+                                                             sampled=sampled)
+    loss, att, ctc = R.joint_loss(ctc_pred, att_pred, y, L, enc_len, cfg['ctc_w'])
+    close(att_pred, d['att_pred'])
+    close(att_map, d['att_map'])
+    close(loss, d['loss'], atol=1e-5)
+    loss.backward()
+    used = [k for k in W if W[k].grad is not None]
+    R.clip_grad_norm([W[k].grad for k in used])
+    for k in used:
+        close(W[k].grad, d['grad.' + k], atol=1e-6)

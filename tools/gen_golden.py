@@ -281,10 +281,25 @@ def _synth_batch(B, T, D, V, Lmax, gen, min_frac=0.6):
     return x, y, lens
 
 
-def ref_step(asr, cfg, x, y, V, n_opt_steps=1):
-    """The arithmetic of Trainer.exec's step body, solver.py:132-182, tf_rate=1.0."""
+def ref_step(asr, cfg, x, y, V, n_opt_steps=1, tf_rate=1.0, record=None):
+    """The arithmetic of Trainer.exec's step body, solver.py:132-182.  tf_rate < 1 (scheduled sampling, asr.py:95-100):
+    `record` receives the values random.random() returned at asr.py:96 and the tokens Categorical.sample() drew at :99."""
     import torch.nn.functional as F
     model = asr.Seq2Seq(x, V, cfg)
+    if record is not None:
+        real_random, real_cat = asr.random.random, asr.Categorical
+
+        def rec_random():
+            v = real_random()
+            record['flip_values'].append(v)
+            return v
+
+        class RecCategorical(real_cat):
+            def sample(self, *a, **k):
+                t = super().sample(*a, **k)
+                record['draws'].append((len(record['flip_values']) - 1, t.clone()))      # the draw that follows flip number ...
+                return t
+        asr.random.random, asr.Categorical = rec_random, RecCategorical
     w0 = _state(model, 'w.')
     seq_loss = torch.nn.CrossEntropyLoss(ignore_index=0, reduction='none')
     ctc_loss_f = torch.nn.CTCLoss(blank=0, reduction='mean')
@@ -296,7 +311,9 @@ def ref_step(asr, cfg, x, y, V, n_opt_steps=1):
         state_len = [int(s) for s in state_len]
         ans_len = int(torch.max(torch.sum(y != 0, dim=-1)))
         opt.zero_grad()
-        ctc_pred, enc_len, att_pred, att_maps = model(x, ans_len, tf_rate=1.0, teacher=y, state_len=state_len)
+        ctc_pred, enc_len, att_pred, att_maps = model(x, ans_len, tf_rate=tf_rate, teacher=y, state_len=state_len)
+        if record is not None:
+            asr.random.random, asr.Categorical = real_random, real_cat
         label = y[:, 1:ans_len + 1].contiguous()
         att_loss, ctc_loss = 0, 0
         if ctc_w < 1:
@@ -339,6 +356,32 @@ def g3_steps(asr, out):
         rec = ref_step(asr, cfg, x, y, V, n_opt_steps=3)
         rec.update({'x': _np(x), 'y': _np(y), 'lens': np.array(lens), 'V': np.array(V)})
         np.savez(os.path.join(out, f'g3_step_{name}.npz'), **rec)
+
+
+def g9_sched_sampling(asr, out):
+    """Scheduled sampling (asr.py:95-100) at tf_rate = 0.5, one optimiser-free step per config: the reference's outputs and
+    gradients together with the coin flips and the sampled tokens it drew, so that a replay (the same flips, the same
+    tokens fed back) must reproduce them.  The seed is chosen so that both branches of the flip occur."""
+    for name in ('dot_att', 'loc_ctc'):
+        cfg = TINY[name]
+        for seed in range(31, 60):
+            _seed(seed)
+            gen = torch.Generator().manual_seed(9)
+            V = 9
+            x, y, lens = _synth_batch(4, 29, 5, V, 6, gen)
+            record = dict(flip_values=[], draws=[])
+            rec = ref_step(asr, cfg, x, y, V, n_opt_steps=1, tf_rate=0.5, record=record)
+            L = len(record['flip_values'])
+            flips = [v <= 0.5 for v in record['flip_values']]
+            n_s = sum(not f for f in flips[:L - 1])
+            if n_s >= 2 and (L - 1 - n_s) >= 2 and np.isfinite(float(rec['loss'])):      # both branches occur before the last step
+                break
+        rec = {k: v for k, v in rec.items() if not k.startswith('w_after.') and not k.startswith('loss_it')}
+        rec.update({'x': _np(x), 'y': _np(y), 'lens': np.array(lens), 'V': np.array(V), 'seed': np.array(seed),
+                    'flip_values': np.array(record['flip_values'], np.float64),
+                    'draw_step': np.array([t for t, _ in record['draws']], np.int64),
+                    'draw_tokens': np.stack([_np(tok) for _, tok in record['draws']]).astype(np.int64)})
+        np.savez(os.path.join(out, f'g9_sched_{name}.npz'), **rec)
 
 
 # ----------------------------------------------------------------------------- G4 trainer trace
@@ -659,6 +702,8 @@ def main():
         g7_valid(Writer, out)
     if want('g8'):
         g8_libri(out)
+    if want('g9'):
+        g9_sched_sampling(asr, out)
     tot = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
     print('wrote', len(os.listdir(out)), 'files,', tot // 1024, 'KiB ->', out)
 

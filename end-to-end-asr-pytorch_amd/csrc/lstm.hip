@@ -709,7 +709,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                 constexpr int OOB = 0x7ffffff0;
                 u32x4 v[SW], got[TAB ? 1 : SW];
                 int off[SW];
-                for (int dl = 0; dl < a.pdelay; ++dl) __builtin_amdgcn_s_sleep(1);
+                for (int dl = 0; dl < (a.pdelay & 255); ++dl) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
                     if constexpr (TAB) off[u] = tabw[2 * u]; else { off[u] = g_off[u]; got[u] = (u32x4){0u, 0u, 0u, 0u}; }
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                 u32x4 v[SW];
                 unsigned got[TAB ? 1 : SW][2];
                 int off[SW];
-                for (int dl = 0; dl < a.pdelay; ++dl) __builtin_amdgcn_s_sleep(1);
+                for (int dl = 0; dl < (a.pdelay & 255); ++dl) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < SW; ++u) {
                     if constexpr (TAB) off[u] = tabw[2 * u]; else { off[u] = g_off[u]; got[u][0] = got[u][1] = 0u; }
@@ -1623,6 +1623,8 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
     }
     GR_ST_PRINT(a.T);
 }
+#include "lstm_x32.h"
+
 size_t bwd_gr_lds(int H, int NB) {
     const int G = (H + 15) / 16, mt = (G + 3) / 4, PS = mt <= 5 ? 20 : mt <= 8 ? 32 : 64, RLD = 16 * PS + 4;
     return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4) +
@@ -1664,7 +1666,7 @@ int check_common(int T, int B, int H, int ND, int sr) {
     return LAS_OK;
 }
 
-void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int concat) {
+void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int concat, int force_ns = 0) {
     a.T = T; a.B = B; a.H = H; a.ND = ND; a.U = U; a.G = (H + U - 1) / U;
     // batch slices: independent sub-recurrences of <= 16 rows each, as many as the chip has room for
     int ns = (B + 11) / 12;
@@ -1676,6 +1678,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
         ns = ns6 < 8 / ND ? (ns6 > ns ? ns6 : ns) : 8 / ND;
     }
     while (ns > 1 && ((long)ND * a.G * ns > las_cu_count() || ns > MAX_SLICES)) --ns;
+    if (force_ns > 0) ns = force_ns;
     a.Bs = (B + ns - 1) / ns;
     a.NS = (B + a.Bs - 1) / a.Bs;
     a.sr = sr; a.concat = concat;
@@ -1695,6 +1698,25 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     a.pdelay = pd ? atoi(pd) : 0;
 }
 int lstm_grid(const LstmArgs& a) { return a.xl ? 8 * a.G * ((a.ND * a.NS + 7) / 8) : a.ND * a.G * a.NS; }
+
+// The 32-unit geometry (lstm_x32.h): bf16, 512 < H <= 1024, slices of <= 16 rows, every group on an XCD of its own.
+inline int host_gr_chunks(int rows) { return (rows >> 4) * 3 + ((rows & 15) + 5) / 6; }
+bool use_x32(int prec, int T, int B, int H, int ND, int sr, int concat, LstmArgs& a) {
+    if (prec != LAS_PREC_BF16 || H <= 512 || H > 1024 || (H & 3)) return false;
+    if (las_fallback("LAS_LSTM_NO_GR") || las_fallback("LAS_LSTM_NO_XL") || las_fallback("LAS_LSTM_NO_X32")) return false;
+    // slices of >= 6 rows while every (direction, slice) group still gets an XCD of its own: the sweeps shrink with the
+    // slice (C5, B = 24: four slices of 6 instead of two of 12: forward 3.7 -> 3.1, backward 6.1 -> 4.8 us per step, C5 step
+    // 55.3 -> 48.6 ms), at the price of occupying all eight XCDs
+    int ns = (B + 5) / 6;
+    if (ns > 8 / ND) ns = 8 / ND;
+    if (ns < (B + 15) / 16) ns = (B + 15) / 16;
+    if (const char* e = LAS_AB_KNOB("LAS_LSTM_X32_NS")) ns = atoi(e);      // (diagnostic build: force the slice count)
+    fill_args(a, T, B, H, ND, 32, sr, concat, ns);
+    if (!a.xl || a.Bs > 16 || a.NS > MAX_SLICES || ND * a.NS > 8) return false;
+    if ((long)T * B * ND * 4 * H * 4 >= (1l << 31)) return false;
+    if ((long)H * host_gr_chunks(a.Bs) > 8 * 256 || (long)a.G * a.Bs * 8 > X32_SWB * 256) return false;
+    return true;
+}
 
 template <int PREC, int NB, int KS>
 int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
@@ -1796,6 +1818,7 @@ extern "C" size_t las_lstm_sync_bytes(void) { return sizeof(SyncWords); }
 extern "C" size_t las_lstm_hx_bytes(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
     if (check_common(T, B, H, ND, 1)) return 0;
+    if (use_x32(prec, T, B, H, ND, 1, 0, a)) return las_align(fwd_gr_ring_bytes(a));
     fill_args(a, T, B, H, ND, 16, 1, 0);
     const size_t esz = prec == LAS_PREC_BF16 ? 2 : 4, vec = prec == LAS_PREC_BF16 ? 8 : 4;
     const size_t plain = (size_t)ND * HX_SLOTS * B * ((H + vec - 1) / vec * vec) * esz;     // [ND][4][B][Hx] ring of lstm_fwd_kernel
@@ -1807,6 +1830,7 @@ extern "C" size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
     BwdPlan p;
     if (check_common(T, B, H, ND, 1)) return 0;
+    if (use_x32(prec, T, B, H, ND, 1, 0, a)) return bwd_x32_ring_bytes(a);
     fill_args(a, T, B, H, ND, 16, 1, 0);
     return bwd_plan(prec, T, B, H, ND, a, p) == LAS_OK ? p.ws : 0;
 }
@@ -1815,6 +1839,7 @@ extern "C" int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
     BwdPlan p;
     if (check_common(T, B, H, ND, 1)) return 0;
+    if (use_x32(prec, T, B, H, ND, 1, 0, a)) return 3;
     fill_args(a, T, B, H, ND, 16, 1, 0);
     if (bwd_plan(prec, T, B, H, ND, a, p) != LAS_OK) return 0;
     return p.gr ? 2 : p.ks ? 1 : 0;
@@ -1824,6 +1849,7 @@ extern "C" int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
     (void)prec;
     if (check_common(T, B, H, ND, 1)) return 0;
+    if (use_x32(prec, T, B, H, ND, 1, 0, a)) return a.ND * a.G * a.NS;
     fill_args(a, T, B, H, ND, 16, 1, 0);
     return a.ND * a.G * a.NS;            // (an XCD-grouped launch starts more, the ones without a group exit at once)
 }
@@ -1838,7 +1864,9 @@ static bool fwd_uses_gr(int prec, int T, int B, int H, int ND, const LstmArgs& a
 }
 extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
     LstmArgs a;
-    if (check_common(T, B, H, ND, 1) || ND * ((H + 15) / 16) > las_cu_count()) return 0;
+    if (check_common(T, B, H, ND, 1)) return 0;
+    if (use_x32(prec, T, B, H, ND, 1, 0, a)) return 2;
+    if (ND * ((H + 15) / 16) > las_cu_count()) return 0;
     fill_args(a, T, B, H, ND, 16, 1, 0);
     const int NB = las_pick_nb(a.Bs), ksteps = (H + 31) / 32;
     int KS = 0;
@@ -1857,9 +1885,31 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     if (rc) return rc;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     int U = 16;
+    LstmArgs a;
+    if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
+        a.y_is_hf = (y == hf);
+        if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
+        hipStream_t st = (hipStream_t)stream;
+        const size_t ringb = fwd_gr_ring_bytes(a);
+        const bool behind = (char*)hx == (char*)sync + sizeof(SyncWords);
+        LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + (behind ? ringb : 0), st));
+        if (!behind) LAS_HIP(hipMemsetAsync(hx, 0, ringb, st));
+        size_t lds = fwd_x32_lds(H);
+        if (lds < MIN_LDS) lds = MIN_LDS;
+#define LAS_X32_FWD(KS_)                                                                                                   \
+    {                                                                                                                     \
+        auto k = lstm_fwd_x32_kernel<KS_>;                                                                                \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(X32_NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf, (u32x4*)hx, \
+                           gates, cs, (SyncWords*)sync, status);                                                          \
+        LAS_LAUNCH_OK();                                                                                                  \
+        return LAS_OK;                                                                                                    \
+    }
+        if ((H + 31) / 32 <= 24) LAS_X32_FWD(24) else LAS_X32_FWD(32)
+#undef LAS_X32_FWD
+    }
     if (ND * ((H + 15) / 16) > las_cu_count()) return LAS_E_UNSUPPORTED;
     // use more, smaller unit slices when the chip has room (shorter MFMA chains per step)
-    LstmArgs a;
     fill_args(a, T, B, H, ND, U, sr, concat);
     if (!a.xl && ND * ((H + 7) / 8) <= las_cu_count() && H >= 512 && H <= 512) {      // (an XCD-grouped launch beats the finer slicing;
         U = 8;                                                            // beyond 512 two batch slices of 16-unit groups do)
@@ -1917,6 +1967,26 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     if (rc) return rc;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     LstmArgs a;
+    if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t ringb = bwd_x32_ring_bytes(a);
+        const bool behind = (char*)dgx == (char*)sync + sizeof(SyncWords);
+        LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + (behind ? ringb : 0), st));
+        if (!behind) LAS_HIP(hipMemsetAsync(dgx, 0, ringb, st));
+        size_t lds = bwd_x32_lds();
+        if (lds < MIN_LDS) lds = MIN_LDS;
+#define LAS_X32_BWD(MT_)                                                                                                   \
+    {                                                                                                                     \
+        auto k = lstm_bwd_x32_kernel<MT_>;                                                                                \
+        LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(X32_NT), lds, st, a, dy, gates, cs, w_hh, lens, (u32x4*)dgx, dgf,   \
+                           (SyncWords*)sync, status);                                                                     \
+        LAS_LAUNCH_OK();                                                                                                  \
+        return LAS_OK;                                                                                                    \
+    }
+        if (((H + 15) / 16 + 7) / 8 <= 6) LAS_X32_BWD(6) else LAS_X32_BWD(8)
+#undef LAS_X32_BWD
+    }
     fill_args(a, T, B, H, ND, 16, sr, concat);
     BwdPlan p;
     rc = bwd_plan(prec, T, B, H, ND, a, p);

@@ -532,7 +532,7 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     sync, hx = sx[:nsync], sx[nsync:]
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
-    kname = 'lstm_fwd_gr_kernel' if L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND)) else 'lstm_fwd_kernel'
+    kname = ('lstm_fwd_kernel', 'lstm_fwd_gr_kernel', 'lstm_fwd_x32_kernel')[L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND))]
     with _Timed(kname, 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
                                   I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), ptr(hx), ptr(gates), ptr(cs),
@@ -557,7 +557,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
     if _ldist._ACTIVE['ex'] is not None:        # gradient buckets in flight on RCCL's stream: do they and this launch both fit?
         _ldist.persistent_launch_guard(L_.las_lstm_resident_wgs(I(prec), I(T), I(B), I(H), I(ND)), dev)
-    with _Timed(('lstm_bwd_kernel', 'lstm_bwd_ks_kernel', 'lstm_bwd_gr_kernel')[ksplit], 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
+    with _Timed(('lstm_bwd_kernel', 'lstm_bwd_ks_kernel', 'lstm_bwd_gr_kernel', 'lstm_bwd_x32_kernel')[ksplit], 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_bwd(I(prec), ptr(gy), ptr(gates), ptr(cs), ptr(w_hh), ptr(lens), I(T), I(B), I(H), I(ND),
                                   I(sr), I(concat), ptr(dgx), ptr(dgf), ptr(sync), ptr(status), cur_stream()),
               'las_lstm_rec_bwd')

@@ -86,8 +86,8 @@ void las_lstm_out_shape(int T, int H, int ND, int sr, int concat, int* T_out, in
 size_t las_lstm_sync_bytes(void);
 size_t las_lstm_hx_bytes(int prec, int T, int B, int H, int ND);        /* size of the `hx` exchange workspace of rec_fwd */
 size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size of the `dgx` exchange workspace of rec_bwd */
-int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* which kernel rec_bwd runs: 2 lstm_bwd_gr_kernel (reduce-scatter of partial dh in tagged granules), 1 lstm_bwd_ks_kernel (the same behind a flag), 0 lstm_bwd_kernel (all-gather of dgates) */
-int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND);       /* which kernel rec_fwd runs: 1 lstm_fwd_gr_kernel (tagged granules), 0 lstm_fwd_kernel */
+int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* which kernel rec_bwd runs: 3 lstm_bwd_x32_kernel (512 < H <= 1024: 32 units per workgroup, every group inside one XCD), 2 lstm_bwd_gr_kernel (reduce-scatter of partial dh in tagged granules), 1 lstm_bwd_ks_kernel (the same behind a flag), 0 lstm_bwd_kernel (all-gather of dgates) */
+int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND);       /* which kernel rec_fwd runs: 2 lstm_fwd_x32_kernel (512 < H <= 1024, 32 units per workgroup), 1 lstm_fwd_gr_kernel (tagged granules), 0 lstm_fwd_kernel */
 int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND);      /* workgroups rec_fwd / rec_bwd keep resident for the whole launch (one per CU, all must be co-resident); callers that overlap other device work with the recurrence (RCCL collectives: dist.py) use it to decide whether that work finds free CUs */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,

@@ -87,23 +87,24 @@ def cpu_baseline(w, cfg, sample_B, steps=1):
     W = {k: (torch.randn(s) / max(1.0, (s[1] if len(s) > 1 else 1) ** 0.5)).numpy() if len(s) > 1 else torch.zeros(s).numpy()
          for k, s in shapes.items()}
     ref = R.RefTrainStep(W, cfg, fast=True)
-    ref.step(x[:1].numpy(), y[:1].numpy())   # untimed: thread pool / allocator warm-up on one utterance
+    ref.step(x.numpy(), y.numpy())           # untimed: thread pool / allocator warm-up on the same sample
     t0 = time.time()
     for _ in range(steps):
         ref.step(x.numpy(), y.numpy())
     dt = time.time() - t0
     frames = sum(lens) * steps
     return dict(value=frames / dt, unit='mel-frames/s', cores=cores, kind='port',
-                sample=f'{steps} full train step(s) of the oracle on the first {sample_B} utterances of the step-0 '
-                       f'synthetic batch (T_max={w["T_max"]}, {frames} real frames, {dt:.1f} s)')
+                sample=f'{steps} full train step(s) of the oracle (after one untimed step) on the first {sample_B} utterances '
+                       f'of the step-0 synthetic batch (T_max={w["T_max"]}, {frames} real frames in all, {dt:.1f} s)')
 
 
 def attach_pmc_traffic(roof, workload):
     """`traffic` = HBM bytes per launch of a single-kernel row from this round's rocprofv3 --pmc passes of THIS command
-    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950),
-    summarised by tools/pmc_summary.py into profiles/r02_pmc_traffic_<workload>.json.  The profiler cannot run inside
-    the bench, so a row whose kernel is not in that file keeps traffic = null."""
-    path = os.path.join(ROOT, 'profiles', f'r02_pmc_traffic_{workload}.json')
+    (FETCH_SIZE and WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; a third
+    pass with SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE gives `mfma_util`, the fraction of the chip's matrix-pipe cycles
+    the launch used), summarised by tools/pmc_summary.py into profiles/r03_pmc_traffic_<workload>.json (tools/r3_profiles.sh).
+    The profiler cannot run inside the bench, so a row whose kernel is not in that file keeps traffic = null."""
+    path = os.path.join(ROOT, 'profiles', f'r03_pmc_traffic_{workload}.json')
     if not os.path.exists(path):
         return
     pmc = json.load(open(path))
@@ -118,17 +119,20 @@ def attach_pmc_traffic(roof, workload):
     for row in [roof] + roof.get('breakdown', []):
         if not row.get('single_kernel'):
             names = group_kernels.get(row['kernel'])
-            per = [[v for n, v in pmc.items() if n.split('<')[0] == k] for k in (names or ())]
+            per = [[v for n, v in pmc.items() if n.split('<')[0] == k and 'hbm_MB_per_launch_corrected' in v] for k in (names or ())]
             if names and per[0]:
                 row['traffic'] = sum(sum(h['hbm_MB_per_launch_corrected'] * h['launches'] for h in hs) / sum(h['launches'] for h in hs)
                                      for hs in per if hs) * 1e6
                 row['traffic_unit'] = 'B/call: one launch each of ' + ' + '.join(k for k, hs in zip(names, per) if hs) + ' (PMC, ' + os.path.basename(path) + ')'
                 row['traffic_stale'] = stale
             continue
-        hits = [v for n, v in pmc.items() if n.split('<')[0] == row['kernel']]
+        hits = [v for n, v in pmc.items() if n.split('<')[0] == row['kernel'] and 'hbm_MB_per_launch_corrected' in v]
         if hits:
             n = sum(h['launches'] for h in hits)
             row['traffic'] = sum(h['hbm_MB_per_launch_corrected'] * h['launches'] for h in hits) / n * 1e6
+            mu = [h['mfma_util'] for h in hits if h.get('mfma_util') is not None]
+            if mu:
+                row['mfma_util_pmc'] = sum(mu) / len(mu)
             row['traffic_unit'] = 'B/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes, ' + os.path.basename(path) + ')'
             row['traffic_stale'] = stale
 
@@ -177,8 +181,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-b', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=1)
+    # CPU baseline sample: 4 utterances of the step-0 batch, one untimed + 3 timed full train steps (~10 s each on 16 cores)
+    ap.add_argument('--cpu-sample-b', type=int, default=4)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     a = ap.parse_args()
     launch_ranks_if_needed(a)
     w = WORKLOADS[a.workload]

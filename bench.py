@@ -181,8 +181,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    # CPU baseline sample: 4 utterances of the step-0 batch, one untimed + 3 timed full train steps (~10 s each on 16 cores)
-    ap.add_argument('--cpu-sample-b', type=int, default=4)
+    # CPU baseline sample: 8 utterances of the step-0 batch, one untimed + 3 timed full train steps (~5 s each on 16 cores at c3)
+    ap.add_argument('--cpu-sample-b', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
     a = ap.parse_args()
     launch_ranks_if_needed(a)

@@ -501,11 +501,24 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         // every WAVE takes the maximum and the sum over the whole utterance for itself (<= 8 elements per lane, DPP
         // reductions): no workgroup reduction, no barrier before the one the context needs anyway (two block reductions
         // and libm expf were 3 600 cycles of the step)
-        float m = -INFINITY;
-        for (int i = lane; i < len; i += 64) m = fmaxf(m, e_l[i]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int i = lane; i < len; i += 64) sum += __expf(e_l[i] - m);
+        // (T' <= 512: the wave's <= 8 elements per lane are loaded ONCE, all requests before the first use; the two loops over
+        // LDS that stood here -- each iteration waiting out the LDS latency behind the previous one's max / exp -- were most of
+        // this phase's 3 700 cycles)
+        float m = -INFINITY, sum = 0.f;
+        if (Tp <= 512) {
+            float ev[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = lane + 64 * k; const float v = e_l[min(i, Tp4 - 1)]; ev[k] = i < len ? v : -INFINITY; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = fmaxf(m, ev[k]);
+            m = wave_max(m);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += __expf(ev[k] - m);            // (exp(-inf) = 0 beyond the utterance)
+        } else {
+            for (int i = lane; i < len; i += 64) m = fmaxf(m, e_l[i]);
+            m = wave_max(m);
+            for (int i = lane; i < len; i += 64) sum += __expf(e_l[i] - m);
+        }
         sum = wave_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
         for (int i = threadIdx.x; i < Tp; i += PNT) att0[LOC_K + i] = i < len ? __expf(e_l[i] - m) * inv : 0.f;
@@ -515,8 +528,21 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         {
             const int cq = threadIdx.x % NQ4, tg = threadIdx.x / NQ4;
             if (tg < NTG) {
+                // four frames per iteration, their eight LDS reads requested before the first FMA (one frame per iteration paid
+                // the LDS latency ~14 times in a row: most of this phase's 3 600 cycles)
                 float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-                for (int tp = tg; tp < len; tp += NTG) {
+                int tp = tg;
+                for (; tp + 3 * NTG < len; tp += 4 * NTG) {
+                    float w[4];
+                    float4 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { w[j] = att0[LOC_K + tp + j * NTG]; v[j] = ld4(enc_l + (size_t)(tp + j * NTG) * ESp + cq * 4); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        c0 = fmaf(w[j], v[j].x, c0); c1 = fmaf(w[j], v[j].y, c1); c2 = fmaf(w[j], v[j].z, c2); c3 = fmaf(w[j], v[j].w, c3);
+                    }
+                }
+                for (; tp < len; tp += NTG) {
                     const float w = att0[LOC_K + tp];
                     const float4 v = ld4(enc_l + (size_t)tp * ESp + cq * 4);
                     c0 = fmaf(w, v.x, c0); c1 = fmaf(w, v.y, c1); c2 = fmaf(w, v.z, c2); c3 = fmaf(w, v.w, c3);
@@ -530,7 +556,13 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             const int kk = threadIdx.x >> 4, l = threadIdx.x & 15, col = 12 * kk + l;
             const bool cv = l < 12 && col < ES;
             float v = 0.f;
-            if (cv) for (int tg = 0; tg < NTG; ++tg) v += part_l[tg * ES + col];
+            if (cv) {                                            // NTG <= 32 partials: every read requested before the first add
+                float pp[32];
+#pragma unroll
+                for (int tg = 0; tg < 32; ++tg) pp[tg] = part_l[min(tg, NTG - 1) * ES + col];
+#pragma unroll
+                for (int tg = 0; tg < 32; ++tg) v += tg < NTG ? pp[tg] : 0.f;
+            }
             v = (cv && col < ESr) ? v : 0.f;
             unsigned w3[3];
             pk_gr_gather12<T>(v, w3);

@@ -536,7 +536,9 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                                                       float* __restrict__ cs, SyncWords* sync, int* status) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, B = a.B, ND = a.ND;
-    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    // (row stride = 16 (mod 32) elements: the 16-lane groups of a ds_read_b128 -- rows 0-3 and 12-15 at one k quarter, rows 4-11 at
+    // the next -- then hit 16 different 16-byte slots of the bank row; with a pad of 8 seven of the 16 lanes collided at H = 320)
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 16;
     const Role role = lstm_role(a);
     if (role.idle) return;
     const int d = role.d, g = role.g, bs = role.bs, j0 = g * 16;
@@ -795,6 +797,7 @@ GR_ST(1);
                         for (int ks = 0; ks < CH; ++ks)
                             hc[(c + 1) & 1][ks] = *(const bf16x8*)(buf + fr * ld + min(((c + 1) * CH + ks) * 32, Kp - 32) + fq * 8);
                     }
+                    __builtin_amdgcn_sched_barrier(0);       // (keep the next chunk's reads in front of this chunk's MFMAs)
 #pragma unroll
                     for (int ks = 0; ks < CH; ++ks) {
                         if (ks & 1) acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[c * CH + ks], hc[c & 1][ks], acc2[0], 0, 0, 0);
@@ -812,6 +815,9 @@ GR_ST(1);
                     for (int bt = 0; bt < NB; ++bt)
                         // (predicating the read on `batch row < Bl` -- 6 of 16 rows in use -- made this phase SLOWER: 580 -> 800 cycles)
                         hv_[ks][bt] = *(const bf16x8*)(buf + (bt * 16 + fr) * ld + min((k0 + ks) * 32, Kp - 32) + fq * 8);
+                // (round 3: without this fence hipcc sinks every read to just in front of its MFMA -- `ds_read; s_waitcnt lgkmcnt(1);
+                // v_mfma` ten times over, each MFMA behind a full LDS latency: 58 cycles per MFMA in the ISA of round 2's build)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < CH; ++ks)
 #pragma unroll
@@ -1300,7 +1306,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                                                          const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
                                                          u32x4* __restrict__ ring, float* __restrict__ dgf,
                                                          SyncWords* sync, int* status) {
-    constexpr int LDK = 64 + 8;                           // own dgates tile: k = gate * 16 + unit
+    constexpr int LDK = 64 + 16;                          // own dgates tile: k = gate * 16 + unit (row stride 160 B: conflict-free b128 fragments)
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, B = a.B, ND = a.ND, K4 = 4 * H, G = a.G;
@@ -1627,7 +1633,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
 
 size_t bwd_gr_lds(int H, int NB) {
     const int G = (H + 15) / 16, mt = (G + 3) / 4, PS = mt <= 5 ? 20 : mt <= 8 ? 32 : 64, RLD = 16 * PS + 4;
-    return (size_t)NB * 16 * (64 + 8) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4) +
+    return (size_t)NB * 16 * (64 + 16) * 2 + sizeof(float) * NB * 16 * (RLD + 2 * (2 * GR_XLD + BG_CLD)) + sizeof(int) * (NB * 16 + 4) +
            (mt > 8 ? sizeof(int) * NT * 12 * 2 : 0);
 }
 size_t bwd_gr_ring_bytes(const LstmArgs& a) { return (size_t)16 * KS_SLOTS * a.ND * a.NS * a.G * a.G * a.Bs * 4; }
@@ -1731,7 +1737,7 @@ int launch_fwd(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj
     return LAS_OK;
 }
 size_t fwd_gr_lds(int H, int NB, int swm = 4) {
-    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 16;
     return (size_t)2 * NB * 16 * ld * 2 + sizeof(float) * 2 * NB * 16 * (2 * GR_XLD + GR_HLD) + sizeof(int) * (NB * 16 + 4) +
            (swm > 4 ? sizeof(int) * NT * swm * 2 : 0);
 }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
     constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = a.H, B = a.B, ND = a.ND;
-    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 16;
     const Role role = lstm_role(a);
     if (role.idle) return;
     const int d = role.d, g = role.g, bs = role.bs, j0 = g * 32;
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
             constexpr int SW = decltype(swc)::value;
             u32x4 v[SW];
             int off[SW];
+            for (int dl = 0; dl < (a.pdelay & 255); ++dl) __builtin_amdgcn_s_sleep(1);      // (diagnostic build: delay the first poll)
 #pragma unroll
             for (int u = 0; u < SW; ++u) { off[u] = g_off[u]; v[u] = gr_poll(rs, off[u]); }
             unsigned spins = 0;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
         f32x4 acc = *(const f32x4*)(xl + fr * X32_XLD + ul * 4) + bias;
         f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0 && !(a.pdelay & 256)) {
-            constexpr int CH = 4, NCH = KS / CH;
+            constexpr int CH = 8, NCH = KS / CH;
             bf16x8 hc[2][CH];
 #pragma unroll
             for (int ks = 0; ks < CH; ++ks) hc[0][ks] = *(const bf16x8*)(buf + fr * ld + min(ks * 32, Kp - 32) + fq * 8);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
                     for (int ks = 0; ks < CH; ++ks)
                         hc[(c + 1) & 1][ks] = *(const bf16x8*)(buf + fr * ld + min(((c + 1) * CH + ks) * 32, Kp - 32) + fq * 8);
                 }
+                __builtin_amdgcn_sched_barrier(0);           // (keep the next chunk's reads in front of this chunk's MFMAs: hipcc sinks them otherwise)
 #pragma unroll
                 for (int ks = 0; ks < CH; ++ks) {
                     if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[c * CH + ks], hc[c & 1][ks], acc2, 0, 0, 0);
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
 }
 
 size_t fwd_x32_lds(int H) {
-    const int Kp = (H + 31) / 32 * 32, ld = Kp + 8;
+    const int Kp = (H + 31) / 32 * 32, ld = Kp + 16;
     return (size_t)2 * 16 * ld * 2 + sizeof(float) * 2 * 16 * (2 * X32_XLD + X32_HLD) + sizeof(int) * (16 + 4);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-constexpr int X32_LDK = 128 + 8;                        // own d-gates tile: k = gate * 32 + unit
+constexpr int X32_LDK = 128 + 16;                       // own d-gates tile: k = gate * 32 + unit
 constexpr int X32_PS = 32, X32_RLD = 32 * X32_PS + 4;   // partial sums [row][column 32][producer 32], rows padded (banks)
 constexpr int X32_SWB = 12;                             // granules a sweeping lane takes per step at most (G * Bs * 8 <= 3072)
 
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_bwd_x32_kernel(LstmArgs a, const 
             constexpr int SW = decltype(swc)::value;
             u32x4 v[SW];
             int off[SW];
+            for (int dl = 0; dl < (a.pdelay & 255); ++dl) __builtin_amdgcn_s_sleep(1);      // (diagnostic build: delay the first poll)
 #pragma unroll
             for (int u = 0; u < SW; ++u) { off[u] = tabw[2 * u]; v[u] = gr_poll(rs, off[u]); }
             precompute(s);                               // under the first poll's round trip

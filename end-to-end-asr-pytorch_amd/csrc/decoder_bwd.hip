@@ -738,7 +738,7 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     const bool fuse_pw = NL == 1;
     const bool drop = d->dropout > 0.f;
     if (pk && chain) {
-        int rc = las_dec_pk_bwd(d, p, enc, enc_len, st_, g_htop, bw_, st);
+        int rc = las_dec_pk_bwd(d, p, enc, psi, enc_len, st_, g_htop, bw_, st);
         if (rc) return rc;
     }
     for (int t = L - 1; t >= 0 && !pk && chain; --t) {

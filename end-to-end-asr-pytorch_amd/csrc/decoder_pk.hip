@@ -55,6 +55,8 @@ struct PkGeom {
 
 struct PkArgs {
     int B, Tp, E, A, C, L;
+    int loc;                            // 1: location-aware attention (asr.py:443-457); 0: dot attention (asr.py:426-432): no conv / u
+                                        // phases, e = psi . q, nothing of f / s saved
     PkGeom g;
     const float* psi; const float* enc; const int32_t* lens;
     const float* xe;                    // [L][B][4C] W_ih[:, 0:C] emb_t + b_ih
@@ -323,13 +325,17 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     }
     for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
         const int k = i % LDK, aa = i / LDK;
-        Wt[i] = to_ct<T>((k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+        Wt[i] = to_ct<T>((a.loc && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
     }
     for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
     for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) cw_l[i] = 0.f;
     __syncthreads();
-    fill_batched<4>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { const int cc = i / LOC_W; cw_l[cc * LWP + (i - cc * LOC_W)] = v; });
-    fill_batched<2>(a.w_e, A, [&](int i, float v) { we_l[i] = v; });
+    if (a.loc) {
+        fill_batched<4>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { const int cc = i / LOC_W; cw_l[cc * LWP + (i - cc * LOC_W)] = v; });
+        fill_batched<2>(a.w_e, A, [&](int i, float v) { we_l[i] = v; });
+    } else {
+        for (int i = threadIdx.x; i < A; i += PNT) we_l[i] = 0.f;
+    }
     for (int i = threadIdx.x; i < Tp4 + 2 * LOC_K + 20; i += PNT) att_l[i] = 0.f;
     __syncthreads();
     for (int i = threadIdx.x; i < len; i += PNT) att0[LOC_K + i] = 1.f / (float)len;      // reference asr.py:444-449
@@ -337,7 +343,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     float wev[NTW];                                              // my a-columns' energy weights (0 beyond A)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? we_l[aa] : 0.f; }
-    const float be = a.b_e[0];
+    const float be = a.loc ? a.b_e[0] : 0.f;
     unsigned* abort_word = a.sync->abort_;
     // the energies all-gather stays inside my utterance: plain granule stores when its parts share an XCD's L2 (checked once)
     const int loc_ = pk_utt_local(&a.sync->utt[b][0], g.NCH, g.xl != 0, abort_word, (int*)(red + 64));
@@ -371,6 +377,8 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         // ---- (A) location features of my frames from the previous attention, u = tanh(W_lp f): needs no q_t.
         // Work item = (channel, 4 consecutive frames, tap segment): 16 FMAs per three 16-byte LDS reads (the scalar form
         // -- two 4-byte reads per FMA -- was bound by LDS instruction issue: 9 400 cycles a step, cycle stamps)
+        float uv[MT][NTW][4];
+        if (a.loc) {
         for (int i = threadIdx.x; i < NSEG * LOC_C * TCq; i += PNT) {
             int sg = cv_sg, cc = cv_cc, qd = cv_qd;                          // (the first item's split is loop-invariant)
             if (i >= PNT) { sg = i / (LOC_C * TCq); const int rem = i - sg * (LOC_C * TCq); cc = rem / TCq; qd = rem - cc * TCq; }
@@ -404,7 +412,6 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         __syncthreads();
         PK_STAMP(0);
         // u = tanh(F W_lp^T): one MFMA k-step per (frame tile, a tile); kept in registers until q_t arrives
-        float uv[MT][NTW][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -417,6 +424,14 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
                     asm volatile("" : "+v"(uv[mt][j][r]));        // done HERE, before the wait for q_t (not sunk behind it)
                 }
             }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) uv[mt][j][r] = 0.f;
+        }
         PK_STAMP(1);
         // ---- (B) q_t from the cell workgroups of my batch slice
         const unsigned tag = (unsigned)t + 1u;
@@ -438,7 +453,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         PK_STAMP(2);
         float qv[NTW];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) qv[j] = q_l[min((wave + PNW * j) * 16 + fr, A - 1)];
+        for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; qv[j] = aa < A ? q_l[aa] : 0.f; }
         // ---- (C) energies of my frames: e = w_e . tanh(psi + q + u) + b_e   (reference asr.py:453); s overwrites u
         float er_[MT][4];
 #pragma unroll
@@ -448,9 +463,13 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    const float sv = fast_tanh(pv[mt][j][r] + qv[j] + uv[mt][j][r]);
-                    uv[mt][j][r] = sv;
-                    acc = fmaf(wev[j], sv, acc);
+                    if (a.loc) {
+                        const float sv = fast_tanh(pv[mt][j][r] + qv[j] + uv[mt][j][r]);
+                        uv[mt][j][r] = sv;
+                        acc = fmaf(wev[j], sv, acc);
+                    } else {
+                        acc = fmaf(pv[mt][j][r], qv[j], acc);      // dot attention: e = psi . q (asr.py:428); columns >= A: q = 0
+                    }
                 }
                 // sum over the 16 a's of my lane row (DPP row_shr 1, 2, 4, 8: lane 15 of the row ends with the total)
                 acc += las_dpp<0x111, 0xf>(0.f, acc);
@@ -577,6 +596,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         }
         // s = tanh(psi + q + u) of my frames, saved for the backward pass: stored only now, after both hand-offs of the
         // step, so that neither waits for these stores (write-only stream: non-temporal)
+        if (a.loc)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -620,7 +640,7 @@ size_t att_lds(int prec, const PkGeom& g, int Tp, int A) {
 }
 
 bool pk_geom(const las_dec_dims* d, PkGeom& best) {
-    if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
+    if (!d || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;      // (dot and location-aware attention)
     if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
     if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
     if (las_fallback("LAS_DEC_NO_PK")) return false;
@@ -702,7 +722,8 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
                    const int32_t* enc_len, las_dec_state* st, hipStream_t stream) {
     PkGeom g;
     if (!pk_geom(d, g)) return LAS_E_UNSUPPORTED;
-    LAS_CHECK_ARG(st->pk_ws && st->pk_status && st->f && st->s && p->conv_w && p->w_lp && p->w_e && p->b_e);
+    LAS_CHECK_ARG(st->pk_ws && st->pk_status);
+    if (d->loc) LAS_CHECK_ARG(st->f && st->s && p->conv_w && p->w_lp && p->w_e && p->b_e);
     const WsLayout w = ws_layout(d, g);
     char* ws = (char*)st->pk_ws;
     const int B = d->B, C = d->C, E = d->E, XI = C + E, L = d->L;
@@ -714,7 +735,7 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
                       (void*)stream);
     if (rc) return rc;
     PkArgs a{};
-    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g;
+    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g; a.loc = d->loc ? 1 : 0;
     a.psi = psi; a.enc = enc; a.lens = enc_len; a.xe = xe;
     a.w_ih = p->w_ih[0]; a.w_hh = p->w_hh[0]; a.b_hh = p->b_hh[0]; a.w_phi = p->w_phi;
     a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e; a.b_e = p->b_e;

@@ -53,8 +53,9 @@ struct PbGeom {
 
 struct PbArgs {
     int B, Tp, E, A, C, L;
+    int loc;                            // 1: location-aware attention; 0: dot attention (no conv / u / d f phases; d e -> d q through psi)
     PbGeom g;
-    const float* enc; const int32_t* lens;
+    const float* enc; const float* psi; const int32_t* lens;
     const float* w_ih; const float* w_hh; const float* w_phi; const float* conv_w; const float* w_lp; const float* w_e;
     // saved by the forward loop
     const float* att; const float* q; const float* gates; const float* cs; const float* f; const float* s;
@@ -351,22 +352,22 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     }
     for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
         const int k = i % LDK, aa = i / LDK;
-        Wt[i] = to_ct<T>((k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+        Wt[i] = to_ct<T>((a.loc && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
     }
     for (int i = threadIdx.x; i < 16 * lda_; i += PNT) {
         const int k = i % lda_, cc = i / lda_;
-        WlT[i] = to_ct<T>((cc < LOC_C && k < A) ? a.w_lp[(long)k * LOC_C + cc] : 0.f);
+        WlT[i] = to_ct<T>((a.loc && cc < LOC_C && k < A) ? a.w_lp[(long)k * LOC_C + cc] : 0.f);
     }
     for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
     for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) {
         const int cc = i / LWP, k = i - cc * LWP;                                // flipped: w'[c][k'] = w[c][2K - k']
-        cwf_l[i] = k < LOC_W ? a.conv_w[cc * LOC_W + (LOC_W - 1 - k)] : 0.f;
+        cwf_l[i] = (a.loc && k < LOC_W) ? a.conv_w[cc * LOC_W + (LOC_W - 1 - k)] : 0.f;
     }
     for (int i = threadIdx.x; i < MT * 16; i += PNT) ct_l[i] = 0.f;
     __syncthreads();
     float wev[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? a.w_e[aa] : 0.f; }
+    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = (a.loc && aa < A) ? a.w_e[aa] : 0.f; }
     unsigned* abort_word = a.sync->abort_;
     unsigned nwait = 0;
     const int loc_ = pk_utt_local(&a.sync->cnt_da[b][0], g.NCH, g.xl != 0, abort_word, flag + 2);
@@ -398,11 +399,22 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             const int i = threadIdx.x + j * PNT;
             if (i < Tp) pf_att[j] = a.att[((long)(t_ + 1) * B + b) * Tp + i];
         }
-        if ((int)threadIdx.x < LOC_C * TC)
+        if (a.loc && (int)threadIdx.x < LOC_C * TC)
             pf_f = pf_tt < TCr ? a.f[(((long)t_ * B + b) * LOC_C + pf_cc) * Tp + r0 + pf_tt] : 0.f;
         pf_q = a.q[((long)t_ * B + b) * A + min(a0 + (int)threadIdx.x, A - 1)];
     };
     prefetch(a.L - 1);
+    if (!a.loc) {                                            // dot attention: d e reaches d q through psi (e = psi . q), the same every step
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tp = min(r0 + mt * 16 + fq * 4 + r, Tp - 1);
+                const float* __restrict__ pp = a.psi + ((long)b * Tp + tp) * A;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; sv[mt][j][r] = aa < A ? pp[aa] : 0.f; }
+            }
+    }
     PK_STAMP_DECL;
 
     for (int t = a.L - 1, n = 1; t >= 0; --t, ++n) {
@@ -412,14 +424,14 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         for (int i = threadIdx.x, j = 0; i < Tp; i += PNT, ++j)
             att_l[i] = j < 2 ? pf_att[j] : a.att[((long)(t + 1) * B + b) * Tp + i];
         if ((int)threadIdx.x < LOC_C * TC) Ft[pf_tt * LDK + pf_cc] = to_ct<T>(pf_f);
-        for (int i = threadIdx.x + PNT; i < LOC_C * TC; i += PNT) {          // (TC > 51: not a geometry this loop is given)
+        for (int i = threadIdx.x + PNT; a.loc && i < LOC_C * TC; i += PNT) {          // (TC > 51: not a geometry this loop is given)
             const int cc = i / TC, tt = i - cc * TC;
             Ft[tt * LDK + cc] = to_ct<T>(tt < TCr ? a.f[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt] : 0.f);
         }
         const float qq_f = pf_q;                                             // (for phase F)
         if (t > 0) prefetch(t - 1);
         PK_STAMP(9);
-        if (t + 1 < a.L) {
+        if (a.loc && t + 1 < a.L) {
             // d f_{t+1} of the frames around my chunk (published by my utterance's parts at the end of step t+1)
             if (!pk_block_wait_x(&a.sync->cnt_df[b][0], g.NCH, (unsigned)(n - 1), local, abort_word, flag + (nwait++ & 1))) {
                 if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
@@ -485,7 +497,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-                mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
+                if (a.loc) mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
                 float uu[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -548,7 +560,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) { dctx_l[threadIdx.x >> 2] = part4; dctxT_l[threadIdx.x >> 2] = to_ct<T>(part4); }
         }
         __syncthreads();
-        load_s(t);                      // requested only now (its 36 registers would be live across the piece sweep): in flight during
+        if (a.loc) load_s(t);           // requested only now (its 36 registers would be live across the piece sweep): in flight during
                                         // the d a product, its exchange and the softmax backward; first used in phase E
         PK_STAMP(11);
         // ---- (C) d a over my E-slice for every frame of the utterance (+ the conv path for my own frames)
@@ -611,8 +623,9 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                     // (frames beyond the utterance: the saved s is undefined there -- the forward loop never writes it --, and 0 * NaN
                     // would poison d q, d f and every gradient behind them; a select, not a product with d e = 0)
                     const float s_ = sv[mt][j][r];
-                    const float dz = tt < tcv ? de * wev[j] * (1.f - s_ * s_) : 0.f;
+                    const float dz = tt < tcv ? (a.loc ? de * wev[j] * (1.f - s_ * s_) : de * s_) : 0.f;      // (dot: s_ holds psi)
                     dq[j] += dz;
+                    if (!a.loc) continue;
                     const int aa = (wave + PNW * j) * 16 + fr;
                     float umv;
                     if constexpr (PREC == LAS_PREC_BF16) umv = (r & 1) ? __uint_as_float(um[mt][j][r >> 1] & 0xffff0000u) : __uint_as_float(um[mt][j][r >> 1] << 16);
@@ -632,7 +645,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         // d f[c][t'] = sum_a d u[t'][a] W_lp[a][c]: MFMA over k = a, the waves split the k-steps, LDS float adds combine them
         // (one wave per 16-frame tile walks all k-steps and keeps the sums in registers: with the k-steps split over the waves
         // the LDS float adds that combined them cost 14 900 cycles a step, cycle stamps)
-        if (wave < MT) {
+        if (a.loc && wave < MT) {
             f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
             mma_rows<PREC, 1>(acc, Du + wave * 16 * lda_, lda_, WlT, lda_, Ap / KSTEP);
 #pragma unroll
@@ -640,18 +653,18 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         }
         __syncthreads();
         PK_STAMP(15);
-        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+        for (int i = threadIdx.x; a.loc && i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
             if (tt < TCr) st_x(a.dfx + (((size_t)(t & 1) * B + b) * LOC_C + cc) * Tp4 + r0 + tt, tt < tcv ? dfa_l[tt * 16 + cc] : 0.f, local);
         }
         PK_STAMP(16);
         pk_signal_x(&a.sync->cnt_dqp[b][0], c, (unsigned)n, local);
-        if (threadIdx.x == PNT - 64) {                      // (the same drain + barrier covers the d f stores)
+        if (a.loc && threadIdx.x == PNT - 64) {             // (the same drain + barrier covers the d f stores)
             if (local) a.sync->cnt_df[b][1 + c] = (unsigned)n;
             else __hip_atomic_fetch_add(&a.sync->cnt_df[b][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PK_STAMP(6);
-        for (int i = threadIdx.x; i < LOC_C * TC; i += PNT) {
+        for (int i = threadIdx.x; a.loc && i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
             if (tt < tcv) __builtin_nontemporal_store(dfa_l[tt * 16 + cc], &a.df[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt]);
         }
@@ -716,7 +729,7 @@ size_t pb_att_lds(int prec, const PbGeom& g, int Tp, int A) {
 }
 
 bool pb_geom(const las_dec_dims* d, PbGeom& best) {
-    if (!d || !d->loc || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;
+    if (!d || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;      // (dot and location-aware attention)
     if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
     if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
     if (las_fallback("LAS_DEC_NO_PK") || LAS_AB_KNOB("LAS_DEC_NO_PK_BWD")) return false;
@@ -789,18 +802,19 @@ size_t las_dec_pk_bwd_ws_bytes(const las_dec_dims* d) {
     return pb_ws(d, g).total;
 }
 
-int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const int32_t* enc_len,
+int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi, const int32_t* enc_len,
                    const las_dec_state* st, const float* g_htop, las_dec_bwd_state* bw, hipStream_t stream) {
     PbGeom g;
     if (!pb_geom(d, g)) return LAS_E_UNSUPPORTED;
-    LAS_CHECK_ARG(bw->pk_ws && bw->pk_status && st->f && st->s && bw->df && bw->de && p->conv_w && p->w_lp && p->w_e);
+    LAS_CHECK_ARG(bw->pk_ws && bw->pk_status && bw->de && psi);
+    if (d->loc) LAS_CHECK_ARG(st->f && st->s && bw->df && p->conv_w && p->w_lp && p->w_e);
     const PbWs w = pb_ws(d, g);
     char* ws = (char*)bw->pk_ws;
     const int B = d->B, C = d->C, E = d->E, L = d->L;
     LAS_HIP(hipMemsetAsync(ws, 0, w.total, stream));
     PbArgs a{};
-    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g;
-    a.enc = enc; a.lens = enc_len;
+    a.B = B; a.Tp = d->Tp; a.E = E; a.A = d->A; a.C = C; a.L = L; a.g = g; a.loc = d->loc ? 1 : 0;
+    a.enc = enc; a.psi = psi; a.lens = enc_len;
     a.w_ih = p->w_ih[0]; a.w_hh = p->w_hh[0]; a.w_phi = p->w_phi; a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e;
     a.att = st->att; a.q = st->q; a.gates = st->gates; a.cs = st->cs; a.f = st->f; a.s = st->s; a.g_htop = g_htop;
     a.dgates = bw->dgates; a.dxin = bw->dxin; a.dq_pre = bw->dq_pre; a.de = bw->de; a.df = bw->df;

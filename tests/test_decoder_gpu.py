@@ -83,7 +83,8 @@ def test_decoder_forward(mods, prec, mode, B, Tp, E, A, C, NL, V, L):
 
 
 @pytest.mark.parametrize('mode,B,Tp,E,A,C,NL,V,L', [('loc', 5, 150, 48, 40, 32, 1, 31, 6), ('dot', 20, 75, 64, 32, 64, 2, 63, 5),
-                                                    ('loc', 24, 300, 640, 300, 320, 1, 31, 4), ('loc', 4, 45, 16, 70, 8, 2, 9, 3)])
+                                                    ('loc', 24, 300, 640, 300, 320, 1, 31, 4), ('loc', 4, 45, 16, 70, 8, 2, 9, 3),
+                                                    ('dot', 6, 75, 64, 48, 32, 1, 63, 7), ('dot', 8, 75, 128, 256, 64, 1, 63, 5)])
 def test_decoder_backward(mods, mode, B, Tp, E, A, C, NL, V, L):
     """BPTT of the whole loop (las_decoder_bwd + the post-loop contractions) vs autograd through the oracle's step
     functions, f32 mode, at sizes with several attention chunks / lanes per row (incl. the C2 shape).  Every gradient
@@ -132,6 +133,8 @@ def test_decoder_backward(mods, mode, B, Tp, E, A, C, NL, V, L):
         got = got.detach().cpu().numpy()
         err, lim = np.abs(got - ref).max(), 2e-5 + 2e-4 * np.abs(ref).max()
         assert err <= lim, (what, float(err), float(lim))
+    if mode == 'dot' and NL == 1:
+        assert dec.DecoderFn.last_pk_bwd_ws is not None, 'dot attention with one Speller layer was meant to take the persistent loops'
     near(h_top, torch.stack(tops), 'h_top')
     near(enc_g.grad, enc_t.grad, 'd enc')
     near(psi_g.grad, psi_t.grad, 'd psi')
@@ -207,6 +210,8 @@ def test_decoder_dropout(mods, NL):
         ref = ref.detach().numpy(); got = got.detach().cpu().numpy()
         err, lim = np.abs(got - ref).max(), 2e-5 + 2e-4 * np.abs(ref).max()
         assert err <= lim, (what, float(err), float(lim))
+    if mode == 'dot' and NL == 1:
+        assert dec.DecoderFn.last_pk_bwd_ws is not None, 'dot attention with one Speller layer was meant to take the persistent loops'
     near(h_top, torch.stack(tops), 'h_top')
     near(enc_g.grad, enc_t.grad, 'd enc')
     near(psi_g.grad, psi_t.grad, 'd psi')
@@ -411,18 +416,22 @@ def test_persistent_bptt_exchange_forms_agree(mods, B, Tp, E, A, C, V, L):
         assert np.abs(a0 - a1).max() <= 1e-6 * np.abs(a1).max() + 1e-9, (k, float(np.abs(a0 - a1).max()), float(np.abs(a1).max()))
 
 
-@pytest.mark.parametrize('B,Tp,E,A,C,V,L', [(12, 150, 128, 96, 64, 31, 12), (24, 300, 640, 300, 320, 31, 5)])
-def test_persistent_loops_bf16_vs_oracle(mods, B, Tp, E, A, C, V, L):
+@pytest.mark.parametrize('mode,B,Tp,E,A,C,V,L', [('loc', 12, 150, 128, 96, 64, 31, 12), ('loc', 24, 300, 640, 300, 320, 31, 5),
+                                                 ('dot', 8, 75, 512, 256, 256, 63, 8)])      # the last: the TIMIT config's decoder (c1)
+def test_persistent_loops_bf16_vs_oracle(mods, mode, B, Tp, E, A, C, V, L):
     """The benchmark's decoder path -- dec_pk_fwd_kernel / dec_pk_bwd_kernel in bf16 mode -- against the ORACLE (autograd
     through attention_step / speller_step), not against another HIP kernel: a mid shape and the C2 / C3 decoder shape, both
     of which take the persistent launches (asserted).  The oracle runs with the operands of the matrix products rounded to
     bf16 as the kernels round them (phi h, W_lp f, the context's enc, the cell's two products), so what is left is the
     rounding of the BACKWARD operands (the exchanged pieces, d q_pre, d u as bf16): forward states to 3e-3, every gradient
-    within 6e-3 of its largest entry (measured: 4.3e-3 at worst; the per-step-vs-persistent comparison above allows 3e-2, as does bf16 mode against pure fp32)."""
+    within 6e-3 of its largest entry (measured: 4.3e-3 at worst; the per-step-vs-persistent comparison above allows 3e-2, as does bf16 mode against pure fp32).
+    Dot attention (e = psi . q sums A = 256 products and is scaled by 2 before the softmax) has a far larger gain from h to the
+    scores than the location-aware form, and the bf16 roundings of the backward operands come back through that gain: measured
+    1.07e-2 at worst (d phi), bound 1.5e-2; the same kernels in fp32 mode meet test_decoder_backward's fp32 bound on dot shapes."""
     from oracle import las_ref as R
     ops, dec = mods
     rng = np.random.RandomState(B * 31 + Tp + L)
-    W = rand_weights(rng, V, C, E, A, 1, True)
+    W = rand_weights(rng, V, C, E, A, 1, mode == 'loc')
     lens = sorted(rng.randint(max(2, Tp // 2), Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
     enc = np.zeros((B, Tp, E), np.float32)
     for b, l in enumerate(lens):
@@ -438,19 +447,19 @@ def test_persistent_loops_bf16_vs_oracle(mods, B, Tp, E, A, C, V, L):
     st['psi'] = psi_t
     tops, atts = [], []
     for t in range(L):
-        a, ctx = R.attention_step(hs[0], enc_t, st, Wt, 'loc', bf16_operands=True)
+        a, ctx = R.attention_step(hs[0], enc_t, st, Wt, mode, bf16_operands=True)
         atts.append(a)
         tops.append(R.speller_step(torch.cat([Wt['embed.weight'][torch.tensor(y[:, t])], ctx], -1), hs, cs, Wt, 1, bf16_operands=True))
     (torch.stack(tops) * torch.tensor(G)).sum().backward()
     # ---- HIP, bf16 mode
-    names = dec.weight_names(1, True)
+    names = dec.weight_names(1, mode == 'loc')
     Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
     enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
     psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     ops.set_precision('bf16')
     h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV), torch.tensor(y, device=DEV),
-                                     L, 1, True, None, dict(seed=0, status=status), *[Wg[k] for k in names])
+                                     L, 1, mode == 'loc', None, dict(seed=0, status=status), *[Wg[k] for k in names])
     (h_top * torch.tensor(G, device=DEV)).sum().backward()
     ops.join_side_stream()
     torch.cuda.synchronize()
@@ -464,4 +473,4 @@ def test_persistent_loops_bf16_vs_oracle(mods, B, Tp, E, A, C, V, L):
         ref = ref.numpy()
         worst[k] = float(np.abs(got.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
     print('persistent decoder bf16 vs oracle, worst / largest entry:', (B, Tp, E, A, C, L), worst)
-    assert max(worst.values()) <= 6e-3, worst
+    assert max(worst.values()) <= (6e-3 if mode == 'loc' else 1.5e-2), worst

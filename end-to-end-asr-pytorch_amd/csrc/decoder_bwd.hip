@@ -73,7 +73,7 @@ struct AttBwdArgs {
 // att_loc_post / att_conv_wgrad after the loop, from the saved s / f / d e / d f.
 // 8 waves per workgroup: a chunk's <= 20 frames are <= 3 per wave, which keeps the two per-frame phases short.
 constexpr int ATT_NW = 8, ATT_NT = 64 * ATT_NW;
-template <bool LOC, int AI>
+template <bool LOC, int AI, int EV = 4>                  // EV: float4 pieces of an enc row per lane (4: E <= 1024, 8: E <= 2048)
 __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[32];
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
             for (int k = 0; k < AI; ++k) svr[r][k] = sp[min(lane + 64 * k, a.A - 1)];
         }
     }
-    // ... and so are this wave's enc rows (<= 4 float4 per lane and row: E <= 1024 on this path)
-    const bool vec = (a.E & 3) == 0 && a.E <= 1024 && ((((uintptr_t)a.enc) & 15) == 0);
-    constexpr int EV = 4;
+    // ... and so are this wave's enc rows (<= EV float4 per lane and row: E <= 256 EV on this path; the 6 x 1024 pBLSTM of
+    // BASELINE configs[4] has E = 2048, and without this path its step was 48.7 us of dependent scalar loads)
+    const bool vec = (a.E & 3) == 0 && a.E <= 256 * EV && ((((uintptr_t)a.enc) & 15) == 0);
     float4 er[ATT_ROWS][EV];
     if (vec) {
 #pragma unroll
@@ -800,11 +800,12 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
             }
         }
         if (!loc) {
-            hipLaunchKernelGGL((att_bwd_step<false, 1>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
+            if (E > 1024) hipLaunchKernelGGL((att_bwd_step<false, 1, 8>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
+            else hipLaunchKernelGGL((att_bwd_step<false, 1, 4>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
         } else {
 #define LAS_ATT_GO(AIV)                                                                                           \
     {                                                                                                             \
-        auto k = att_bwd_step<true, AIV>;                                                                         \
+        auto k = E > 1024 ? att_bwd_step<true, AIV, 8> : att_bwd_step<true, AIV, 4>;                              \
         if (lds_e > 64 * 1024 && t == L - 1) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e)); \
         hipLaunchKernelGGL(k, dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);                                          \
     }

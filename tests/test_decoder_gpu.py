@@ -84,7 +84,10 @@ def test_decoder_forward(mods, prec, mode, B, Tp, E, A, C, NL, V, L):
 
 @pytest.mark.parametrize('mode,B,Tp,E,A,C,NL,V,L', [('loc', 5, 150, 48, 40, 32, 1, 31, 6), ('dot', 20, 75, 64, 32, 64, 2, 63, 5),
                                                     ('loc', 24, 300, 640, 300, 320, 1, 31, 4), ('loc', 4, 45, 16, 70, 8, 2, 9, 3),
-                                                    ('dot', 6, 75, 64, 48, 32, 1, 63, 7), ('dot', 8, 75, 128, 256, 64, 1, 63, 5)])
+                                                    ('dot', 6, 75, 64, 48, 32, 1, 63, 7), ('dot', 8, 75, 128, 256, 64, 1, 63, 5),
+                                                    # E > 1024 on the per-step chain (two Speller layers keep it off the persistent loops):
+                                                    # att_bwd_step's 8-piece row path (the 6 x 1024 pBLSTM has E = 2048)
+                                                    ('loc', 3, 45, 1280, 70, 8, 2, 9, 3), ('dot', 3, 40, 2048, 32, 8, 2, 9, 3)])
 def test_decoder_backward(mods, mode, B, Tp, E, A, C, NL, V, L):
     """BPTT of the whole loop (las_decoder_bwd + the post-loop contractions) vs autograd through the oracle's step
     functions, f32 mode, at sizes with several attention chunks / lanes per row (incl. the C2 shape).  Every gradient

@@ -272,7 +272,8 @@ __device__ __forceinline__ void pk_cell_role(const PkArgs& a, char* smem) {
 // is an MFMA product (F: frames x 10 channels from the location conv, zero padded to one k-step), and psi / u / s live in
 // registers in that product's output layout: lane (fr = lane & 15, fq = lane >> 4) holds frames 16 mt + 4 fq + r, r = 0..3,
 // of a = 16 (wave + 8 j) + fr.
-template <int PREC, int MT, int NTW>
+template <int PREC, int MT, int NTW, bool LOC>      // LOC: location-aware attention (false: dot -- no conv / u / d f phases); a
+// compile-time switch: as a run-time flag it cost the location-aware BPTT loop 0.7 ms at c3 (registers, 16 spilled)
 __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     typedef typename CT<PREC>::T T;
     constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
@@ -325,12 +326,12 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     }
     for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
         const int k = i % LDK, aa = i / LDK;
-        Wt[i] = to_ct<T>((a.loc && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+        Wt[i] = to_ct<T>((LOC && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
     }
     for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
     for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) cw_l[i] = 0.f;
     __syncthreads();
-    if (a.loc) {
+    if (LOC) {
         fill_batched<4>(a.conv_w, LOC_C * LOC_W, [&](int i, float v) { const int cc = i / LOC_W; cw_l[cc * LWP + (i - cc * LOC_W)] = v; });
         fill_batched<2>(a.w_e, A, [&](int i, float v) { we_l[i] = v; });
     } else {
@@ -343,7 +344,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     float wev[NTW];                                              // my a-columns' energy weights (0 beyond A)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = aa < A ? we_l[aa] : 0.f; }
-    const float be = a.loc ? a.b_e[0] : 0.f;
+    const float be = LOC ? a.b_e[0] : 0.f;
     unsigned* abort_word = a.sync->abort_;
     // the energies all-gather stays inside my utterance: plain granule stores when its parts share an XCD's L2 (checked once)
     const int loc_ = pk_utt_local(&a.sync->utt[b][0], g.NCH, g.xl != 0, abort_word, (int*)(red + 64));
@@ -378,7 +379,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         // Work item = (channel, 4 consecutive frames, tap segment): 16 FMAs per three 16-byte LDS reads (the scalar form
         // -- two 4-byte reads per FMA -- was bound by LDS instruction issue: 9 400 cycles a step, cycle stamps)
         float uv[MT][NTW][4];
-        if (a.loc) {
+        if (LOC) {
         for (int i = threadIdx.x; i < NSEG * LOC_C * TCq; i += PNT) {
             int sg = cv_sg, cc = cv_cc, qd = cv_qd;                          // (the first item's split is loop-invariant)
             if (i >= PNT) { sg = i / (LOC_C * TCq); const int rem = i - sg * (LOC_C * TCq); cc = rem / TCq; qd = rem - cc * TCq; }
@@ -463,7 +464,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    if (a.loc) {
+                    if (LOC) {
                         const float sv = fast_tanh(pv[mt][j][r] + qv[j] + uv[mt][j][r]);
                         uv[mt][j][r] = sv;
                         acc = fmaf(wev[j], sv, acc);
@@ -596,7 +597,7 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         }
         // s = tanh(psi + q + u) of my frames, saved for the backward pass: stored only now, after both hand-offs of the
         // step, so that neither waits for these stores (write-only stream: non-temporal)
-        if (a.loc)
+        if (LOC)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -616,11 +617,11 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
     PK_STAMP_FLUSH(a.dbg);
 }
 
-template <int PREC, int NB, int MT, int NTW>
+template <int PREC, int NB, int MT, int NTW, bool LOC>
 __global__ __launch_bounds__(PNT) void dec_pk_fwd_kernel(PkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.g.NCELL) pk_cell_role<PREC, NB>(a, smem);
-    else pk_att_role<PREC, MT, NTW>(a, smem);
+    else pk_att_role<PREC, MT, NTW, LOC>(a, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -746,7 +747,7 @@ int las_dec_pk_fwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     const int grid = g.NCELL + (g.xl ? 8 * ((B + 7) / 8) * g.NCH : B * g.NCH);
 #define LAS_PK_GO(P_, N_, M_, W_)                                                                                  \
     {                                                                                                             \
-        auto k = dec_pk_fwd_kernel<P_, N_, M_, W_>;                                                               \
+        auto k = a.loc ? dec_pk_fwd_kernel<P_, N_, M_, W_, true> : dec_pk_fwd_kernel<P_, N_, M_, W_, false>;                                                               \
         LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
         hipLaunchKernelGGL(k, dim3(grid), dim3(PNT), g.lds, stream, a);                                           \
         LAS_LAUNCH_OK();                                                                                          \

@@ -290,7 +290,8 @@ __host__ __device__ inline int pb_window_vecs(int TCq) {
     return need + ((TCq - need) % 16 + 16) % 16;
 }
 
-template <int PREC, int MT, int NTW>
+template <int PREC, int MT, int NTW, bool LOC>      // LOC: location-aware attention (false: dot -- no conv / u / d f phases); a
+// compile-time switch: as a run-time flag it cost the location-aware BPTT loop 0.7 ms at c3 (registers, 16 spilled)
 __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     typedef typename CT<PREC>::T T;
     constexpr int VEC = CT<PREC>::VEC, KSTEP = CT<PREC>::KSTEP, LDK = KSTEP + VEC;
@@ -352,22 +353,22 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     }
     for (int i = threadIdx.x; i < NTW * PNW * 16 * LDK; i += PNT) {
         const int k = i % LDK, aa = i / LDK;
-        Wt[i] = to_ct<T>((a.loc && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
+        Wt[i] = to_ct<T>((LOC && k < LOC_C && aa < A) ? a.w_lp[(long)aa * LOC_C + k] : 0.f);
     }
     for (int i = threadIdx.x; i < 16 * lda_; i += PNT) {
         const int k = i % lda_, cc = i / lda_;
-        WlT[i] = to_ct<T>((a.loc && cc < LOC_C && k < A) ? a.w_lp[(long)k * LOC_C + cc] : 0.f);
+        WlT[i] = to_ct<T>((LOC && cc < LOC_C && k < A) ? a.w_lp[(long)k * LOC_C + cc] : 0.f);
     }
     for (int i = threadIdx.x; i < MT * 16 * LDK; i += PNT) Ft[i] = (T)0;
     for (int i = threadIdx.x; i < LOC_C * LWP; i += PNT) {
         const int cc = i / LWP, k = i - cc * LWP;                                // flipped: w'[c][k'] = w[c][2K - k']
-        cwf_l[i] = (a.loc && k < LOC_W) ? a.conv_w[cc * LOC_W + (LOC_W - 1 - k)] : 0.f;
+        cwf_l[i] = (LOC && k < LOC_W) ? a.conv_w[cc * LOC_W + (LOC_W - 1 - k)] : 0.f;
     }
     for (int i = threadIdx.x; i < MT * 16; i += PNT) ct_l[i] = 0.f;
     __syncthreads();
     float wev[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = (a.loc && aa < A) ? a.w_e[aa] : 0.f; }
+    for (int j = 0; j < NTW; ++j) { const int aa = (wave + PNW * j) * 16 + fr; wev[j] = (LOC && aa < A) ? a.w_e[aa] : 0.f; }
     unsigned* abort_word = a.sync->abort_;
     unsigned nwait = 0;
     const int loc_ = pk_utt_local(&a.sync->cnt_da[b][0], g.NCH, g.xl != 0, abort_word, flag + 2);
@@ -399,12 +400,12 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             const int i = threadIdx.x + j * PNT;
             if (i < Tp) pf_att[j] = a.att[((long)(t_ + 1) * B + b) * Tp + i];
         }
-        if (a.loc && (int)threadIdx.x < LOC_C * TC)
+        if (LOC && (int)threadIdx.x < LOC_C * TC)
             pf_f = pf_tt < TCr ? a.f[(((long)t_ * B + b) * LOC_C + pf_cc) * Tp + r0 + pf_tt] : 0.f;
         pf_q = a.q[((long)t_ * B + b) * A + min(a0 + (int)threadIdx.x, A - 1)];
     };
     prefetch(a.L - 1);
-    if (!a.loc) {                                            // dot attention: d e reaches d q through psi (e = psi . q), the same every step
+    if (!LOC) {                                            // dot attention: d e reaches d q through psi (e = psi . q), the same every step
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -424,14 +425,14 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         for (int i = threadIdx.x, j = 0; i < Tp; i += PNT, ++j)
             att_l[i] = j < 2 ? pf_att[j] : a.att[((long)(t + 1) * B + b) * Tp + i];
         if ((int)threadIdx.x < LOC_C * TC) Ft[pf_tt * LDK + pf_cc] = to_ct<T>(pf_f);
-        for (int i = threadIdx.x + PNT; a.loc && i < LOC_C * TC; i += PNT) {          // (TC > 51: not a geometry this loop is given)
+        for (int i = threadIdx.x + PNT; LOC && i < LOC_C * TC; i += PNT) {          // (TC > 51: not a geometry this loop is given)
             const int cc = i / TC, tt = i - cc * TC;
             Ft[tt * LDK + cc] = to_ct<T>(tt < TCr ? a.f[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt] : 0.f);
         }
         const float qq_f = pf_q;                                             // (for phase F)
         if (t > 0) prefetch(t - 1);
         PK_STAMP(9);
-        if (a.loc && t + 1 < a.L) {
+        if (LOC && t + 1 < a.L) {
             // d f_{t+1} of the frames around my chunk (published by my utterance's parts at the end of step t+1)
             if (!pk_block_wait_x(&a.sync->cnt_df[b][0], g.NCH, (unsigned)(n - 1), local, abort_word, flag + (nwait++ & 1))) {
                 if (threadIdx.x == 0) *a.status = LAS_E_TIMEOUT;
@@ -497,7 +498,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-                if (a.loc) mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
+                if (LOC) mma_rows<PREC, 1>(acc, Ft + mt * 16 * LDK, LDK, Wt + (wave + PNW * j) * 16 * LDK, LDK, 1);
                 float uu[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -560,7 +561,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             if (threadIdx.x < 4 * ES && (threadIdx.x & 3) == 3) { dctx_l[threadIdx.x >> 2] = part4; dctxT_l[threadIdx.x >> 2] = to_ct<T>(part4); }
         }
         __syncthreads();
-        if (a.loc) load_s(t);           // requested only now (its 36 registers would be live across the piece sweep): in flight during
+        if (LOC) load_s(t);           // requested only now (its 36 registers would be live across the piece sweep): in flight during
                                         // the d a product, its exchange and the softmax backward; first used in phase E
         PK_STAMP(11);
         // ---- (C) d a over my E-slice for every frame of the utterance (+ the conv path for my own frames)
@@ -623,9 +624,9 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                     // (frames beyond the utterance: the saved s is undefined there -- the forward loop never writes it --, and 0 * NaN
                     // would poison d q, d f and every gradient behind them; a select, not a product with d e = 0)
                     const float s_ = sv[mt][j][r];
-                    const float dz = tt < tcv ? (a.loc ? de * wev[j] * (1.f - s_ * s_) : de * s_) : 0.f;      // (dot: s_ holds psi)
+                    const float dz = tt < tcv ? (LOC ? de * wev[j] * (1.f - s_ * s_) : de * s_) : 0.f;      // (dot: s_ holds psi)
                     dq[j] += dz;
-                    if (!a.loc) continue;
+                    if (!LOC) continue;
                     const int aa = (wave + PNW * j) * 16 + fr;
                     float umv;
                     if constexpr (PREC == LAS_PREC_BF16) umv = (r & 1) ? __uint_as_float(um[mt][j][r >> 1] & 0xffff0000u) : __uint_as_float(um[mt][j][r >> 1] << 16);
@@ -645,7 +646,7 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         // d f[c][t'] = sum_a d u[t'][a] W_lp[a][c]: MFMA over k = a, the waves split the k-steps, LDS float adds combine them
         // (one wave per 16-frame tile walks all k-steps and keeps the sums in registers: with the k-steps split over the waves
         // the LDS float adds that combined them cost 14 900 cycles a step, cycle stamps)
-        if (a.loc && wave < MT) {
+        if (LOC && wave < MT) {
             f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
             mma_rows<PREC, 1>(acc, Du + wave * 16 * lda_, lda_, WlT, lda_, Ap / KSTEP);
 #pragma unroll
@@ -653,18 +654,18 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
         }
         __syncthreads();
         PK_STAMP(15);
-        for (int i = threadIdx.x; a.loc && i < LOC_C * TC; i += PNT) {
+        for (int i = threadIdx.x; LOC && i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
             if (tt < TCr) st_x(a.dfx + (((size_t)(t & 1) * B + b) * LOC_C + cc) * Tp4 + r0 + tt, tt < tcv ? dfa_l[tt * 16 + cc] : 0.f, local);
         }
         PK_STAMP(16);
         pk_signal_x(&a.sync->cnt_dqp[b][0], c, (unsigned)n, local);
-        if (a.loc && threadIdx.x == PNT - 64) {             // (the same drain + barrier covers the d f stores)
+        if (LOC && threadIdx.x == PNT - 64) {             // (the same drain + barrier covers the d f stores)
             if (local) a.sync->cnt_df[b][1 + c] = (unsigned)n;
             else __hip_atomic_fetch_add(&a.sync->cnt_df[b][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PK_STAMP(6);
-        for (int i = threadIdx.x; a.loc && i < LOC_C * TC; i += PNT) {
+        for (int i = threadIdx.x; LOC && i < LOC_C * TC; i += PNT) {
             const int cc = i / TC, tt = i - cc * TC;
             if (tt < tcv) __builtin_nontemporal_store(dfa_l[tt * 16 + cc], &a.df[(((long)t * B + b) * LOC_C + cc) * Tp + r0 + tt]);
         }
@@ -705,11 +706,11 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
     PK_STAMP_FLUSH(a.dbg);
 }
 
-template <int PREC, int NB, int MT, int NTW>
+template <int PREC, int NB, int MT, int NTW, bool LOC>
 __global__ __launch_bounds__(PNT) void dec_pk_bwd_kernel(PbArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < a.g.NCELL) pb_cell_role<PREC, NB>(a, smem);
-    else pb_att_role<PREC, MT, NTW>(a, smem);
+    else pb_att_role<PREC, MT, NTW, LOC>(a, smem);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -824,7 +825,7 @@ int las_dec_pk_bwd(const las_dec_dims* d, const las_dec_params* p, const float* 
     int launched = 0;
 #define LAS_PB_GO(P_, N_, M_, W_)                                                                                  \
     {                                                                                                             \
-        auto k = dec_pk_bwd_kernel<P_, N_, M_, W_>;                                                               \
+        auto k = a.loc ? dec_pk_bwd_kernel<P_, N_, M_, W_, true> : dec_pk_bwd_kernel<P_, N_, M_, W_, false>;                                                               \
         LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));     \
         hipLaunchKernelGGL(k, dim3(grid), dim3(PNT), g.lds, stream, a);                                           \
         LAS_LAUNCH_OK();                                                                                          \

@@ -3,6 +3,7 @@
 #include "las_common.h"
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 // Operand ("compute") type per precision mode.
 template <int PREC> struct CT;

@@ -194,6 +194,8 @@ struct LstmArgs {
                               // backward kernel's dgf measured neutral)
     int pf;                   // forward: a fifth wave prefetches the x-projection rows into the L2 two steps ahead
     int pdelay;               // (diagnostic build) granule kernels: units of 64 cycles to sleep before a step's first poll
+    void* tw;                 // bf16 twin of the launch's main output (forward: y; backward: d gates), written by the granule /
+                              // 32-unit kernels next to the fp32 stores (the GEMMs behind the layer read it); null: none
 };
 
 // Which (direction d, unit slice g, batch slice bs) a workgroup works on.  A GROUP = the G workgroups of one
@@ -574,6 +576,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
         __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hf, 0, (int)(nrow * ND * H * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * ND * H * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t ry16 = __builtin_amdgcn_make_buffer_rsrc(a.tw, 0, a.tw ? (int)((long)a.T_out * B * a.F_out * 2) : 0, 0x00020000);
         auto tstep = [&](int s) { const int sc = min(s, a.T - 1); return d == 0 ? sc : a.T - 1 - sc; };
         auto xload = [&](int s, u32x4 (&xr)[NQ]) {
             const int t = tstep(s);
@@ -619,6 +622,10 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                 __builtin_amdgcn_raw_buffer_store_b128(hv4, rh, off, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b128(cv4, rc, off, 0, 2);
                 __builtin_amdgcn_raw_buffer_store_b128(hv4, ry, offy, 0, 2);
+                // y's bf16 twin (an empty resource when there is none: every offset is out of range)
+                const int off16 = a.y_is_hf ? off : ((ok && yok) ? (int)(yo * 4) : OOB);
+                const u32x2 h16 = {pack_bf16x2(__uint_as_float(hv4[0]), __uint_as_float(hv4[1])), pack_bf16x2(__uint_as_float(hv4[2]), __uint_as_float(hv4[3]))};
+                __builtin_amdgcn_raw_buffer_store_b64(h16, ry16, off16 == OOB ? OOB : off16 >> 1, 0, 0);
             }
         };
         u32x4 x0[NQ], x1[NQ], x2[NQ];                    // three sets: a value is used three phases after its request
@@ -1345,6 +1352,7 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
         __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * NDH * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc((void*)dgf, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t ro16 = __builtin_amdgcn_make_buffer_rsrc(a.tw, 0, a.tw ? (int)(nrow * ND4H * 2) : 0, 0x00020000);
         struct In { u32x4 g4[NQ], c[NB], cp[NB], y[NB]; };
         auto xload = [&](int s, In& x) {
             const int t = tstep(s), tp = d == 0 ? t - 1 : t + 1;
@@ -1393,6 +1401,8 @@ __global__ __launch_bounds__(NT + 64) void lstm_bwd_gr_kernel(LstmArgs a, const 
                 const u32x4 v = {p[0], p[4], p[8], p[12]};
                 const int off = (valid && row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * K4 + gi * H + j0 + u0) * 4) : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(v, ro_, off, 0, 0);
+                const u32x2 v16 = {pack_bf16x2(__uint_as_float(v[0]), __uint_as_float(v[1])), pack_bf16x2(__uint_as_float(v[2]), __uint_as_float(v[3]))};
+                __builtin_amdgcn_raw_buffer_store_b64(v16, ro16, off == OOB ? OOB : off >> 1, 0, 0);      // the bf16 twin (empty resource: none)
             }
         };
         In x0, x1, x2;                                   // three sets: a value is used three phases after its request
@@ -1883,9 +1893,29 @@ extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
     return fwd_uses_gr(prec, T, B, H, ND, a, u8 ? 8 : 16, NB, KS) ? 1 : 0;
 }
 
+static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
+                        const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
+                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
+
+// y_bf16 (may be null): the bf16 twin of y, [T_out][B][F_out] -- the operand of the projection GEMM behind the layer.  The granule
+// and 32-unit kernels write it next to the fp32 stores (no second pass over y); behind the other kernels it is one cast pass.
 extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                                 const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
-                                float* hf, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
+                                float* hf, void* y_bf16, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
+    bool in_kernel = false;
+    int rc = rec_fwd_impl(prec, xproj, b_ih, b_hh, w_hh, lens, T, B, H, ND, sr, concat, y, hf, y_bf16, &in_kernel, hx, gates,
+                          cs, sync, status, stream);
+    if (rc == LAS_OK && y_bf16 && !in_kernel) {
+        int T_out, F_out;
+        las_lstm_out_shape(T, H, ND, sr, concat, &T_out, &F_out);
+        rc = las_cast_bf16(y, y_bf16, (int64_t)T_out * B * F_out, stream);
+    }
+    return rc;
+}
+
+static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
+                        const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
+                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
     LAS_CHECK_ARG(xproj && b_ih && b_hh && w_hh && lens && y && hf && hx && gates && cs && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
@@ -1894,6 +1924,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     LstmArgs a;
     if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
         a.y_is_hf = (y == hf);
+        a.tw = tw; *tw_done = true;
         if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
         hipStream_t st = (hipStream_t)stream;
         const size_t ringb = fwd_gr_ring_bytes(a);
@@ -1936,6 +1967,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     size_t lds = fwd_lds(prec, H, NB, KS > 0);
     if (lds > LDS_CAP) return LAS_E_UNSUPPORTED;
     a.y_is_hf = (y == hf);
+    a.tw = tw;
     if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
     if (lds < MIN_LDS) lds = MIN_LDS;
     hipStream_t st = (hipStream_t)stream;
@@ -1944,6 +1976,7 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + ((gr_fwd && (char*)hx == (char*)sync + sizeof(SyncWords)) ? fwd_gr_ring_bytes(a) : 0), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
     if (gr_fwd) {
+        *tw_done = true;
         // tagged-granule hand-off (lstm_fwd_gr_kernel): no flag, no drain, one barrier per step
         lds = fwd_gr_lds(H, NB);
         if (lds < MIN_LDS) lds = MIN_LDS;
@@ -1965,15 +1998,31 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
     return LAS_E_BADARG;
 }
 
+static int rec_bwd_impl(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
+                        const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx,
+                        float* dgf, void* tw, bool* tw_done, void* sync, int* status, void* stream);
+
+// dgf_bf16 (may be null): the bf16 twin of dgf, [T][B][ND*4H] -- the operand of the d x / d W_ih / d W_hh GEMMs behind the launch;
+// written by the granule and 32-unit kernels themselves, one cast pass behind the others.
 extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
                                 const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx,
-                                float* dgf, void* sync, int* status, void* stream) {
+                                float* dgf, void* dgf_bf16, void* sync, int* status, void* stream) {
+    bool in_kernel = false;
+    int rc = rec_bwd_impl(prec, dy, gates, cs, w_hh, lens, T, B, H, ND, sr, concat, dgx, dgf, dgf_bf16, &in_kernel, sync, status, stream);
+    if (rc == LAS_OK && dgf_bf16 && !in_kernel) rc = las_cast_bf16(dgf, dgf_bf16, (int64_t)T * B * ND * 4 * H, stream);
+    return rc;
+}
+
+static int rec_bwd_impl(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
+                        const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx,
+                        float* dgf, void* tw, bool* tw_done, void* sync, int* status, void* stream) {
     LAS_CHECK_ARG(dy && gates && cs && w_hh && lens && dgx && dgf && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
     if (prec != LAS_PREC_BF16 && prec != LAS_PREC_F32) return LAS_E_BADARG;
     LstmArgs a;
     if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
+        a.tw = tw; *tw_done = true;
         hipStream_t st = (hipStream_t)stream;
         const size_t ringb = bwd_x32_ring_bytes(a);
         const bool behind = (char*)dgx == (char*)sync + sizeof(SyncWords);
@@ -1999,11 +2048,13 @@ extern "C" int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, c
     if (rc) return rc;
     const int NB = p.NB, NC = p.NC, K4p = p.K4p;
     a.wdirect = p.wdirect ? 1 : 0;
+    a.tw = tw;
     const size_t lds = p.lds;
     hipStream_t st = (hipStream_t)stream;
     const bool ring_behind = p.gr && (char*)dgx == (char*)sync + sizeof(SyncWords);      // one fill for both
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + (ring_behind ? p.ws : 0), st));
     if (p.gr) {
+        *tw_done = true;
         if (!ring_behind) LAS_HIP(hipMemsetAsync(dgx, 0, p.ws, st));      // tags of earlier launches must not match
 #define LAS_GR_GO(N_, M_)                                                                                              \
     {                                                                                                                 \

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
     const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hf, 0, (int)(nrow * NDH * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * NDH * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry16 = __builtin_amdgcn_make_buffer_rsrc(a.tw, 0, a.tw ? (int)((long)a.T_out * B * a.F_out * 2) : 0, 0x00020000);
     auto tstep = [&](int s) __attribute__((always_inline)) { const int sc = min(s, a.T - 1); return d == 0 ? sc : a.T - 1 - sc; };
     auto xload = [&](int s, u32x4 (&xr)[2]) __attribute__((always_inline)) {
         const int t = tstep(s);
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
             __builtin_amdgcn_raw_buffer_store_b128(hv4, rh, off, 0, 2);
             __builtin_amdgcn_raw_buffer_store_b128(cv4, rc, off, 0, 2);
             __builtin_amdgcn_raw_buffer_store_b128(hv4, ry, offy, 0, 2);
+            // y's bf16 twin (an empty resource when there is none: every offset is out of range)
+            const int off16 = a.y_is_hf ? off : ((ok && yok) ? (int)(yo * 4) : OOB);
+            const u32x2 h16 = {pack_bf16x2(__uint_as_float(hv4[0]), __uint_as_float(hv4[1])), pack_bf16x2(__uint_as_float(hv4[2]), __uint_as_float(hv4[3]))};
+            __builtin_amdgcn_raw_buffer_store_b64(h16, ry16, off16 == OOB ? OOB : off16 >> 1, 0, 0);
         }
     };
 
@@ -403,6 +408,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_bwd_x32_kernel(LstmArgs a, const 
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * NDH * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((long)a.T_out * B * a.F_out * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc((void*)dgf, 0, (int)(nrow * ND4H * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro16 = __builtin_amdgcn_make_buffer_rsrc(a.tw, 0, a.tw ? (int)(nrow * ND4H * 2) : 0, 0x00020000);
     struct In { u32x4 g4[2], c, cp, y; };
     auto xload = [&](int s, In& x) __attribute__((always_inline)) {
         const int t = tstep(s), tp = d == 0 ? t - 1 : t + 1;
@@ -449,6 +455,8 @@ __global__ __launch_bounds__(X32_NT) void lstm_bwd_x32_kernel(LstmArgs a, const 
             const u32x4 v = {p[0], p[4], p[8], p[12]};
             const int off = (row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * K4 + gi * H + j0 + u0) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(v, ro_, off, 0, 0);
+            const u32x2 v16 = {pack_bf16x2(__uint_as_float(v[0]), __uint_as_float(v[1])), pack_bf16x2(__uint_as_float(v[2]), __uint_as_float(v[3]))};
+            __builtin_amdgcn_raw_buffer_store_b64(v16, ro16, off == OOB ? OOB : off >> 1, 0, 0);      // the bf16 twin (empty resource: none)
         }
     };
 

@@ -89,12 +89,15 @@ size_t las_lstm_bwd_ws_bytes(int prec, int T, int B, int H, int ND);   /* size o
 int las_lstm_bwd_is_ksplit(int prec, int T, int B, int H, int ND);     /* which kernel rec_bwd runs: 3 lstm_bwd_x32_kernel (512 < H <= 1024: 32 units per workgroup, every group inside one XCD), 2 lstm_bwd_gr_kernel (reduce-scatter of partial dh in tagged granules), 1 lstm_bwd_ks_kernel (the same behind a flag), 0 lstm_bwd_kernel (all-gather of dgates) */
 int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND);       /* which kernel rec_fwd runs: 2 lstm_fwd_x32_kernel (512 < H <= 1024, 32 units per workgroup), 1 lstm_fwd_gr_kernel (tagged granules), 0 lstm_fwd_kernel */
 int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND);      /* workgroups rec_fwd / rec_bwd keep resident for the whole launch (one per CU, all must be co-resident); callers that overlap other device work with the recurrence (RCCL collectives: dist.py) use it to decide whether that work finds free CUs */
+/* y_bf16 / dgf_bf16 (may be null): bf16 twins of y [T_out][B][F_out] / dgf [T][B][ND*4H], the operands of the GEMMs behind the
+ * launch (projection; d x, d W_ih, d W_hh).  The granule and 32-unit kernels write them next to the fp32 stores; behind the
+ * other kernels the call appends one cast pass. */
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
-                     void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
+                     void* y_bf16, void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
 int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx, float* dgf,
-                     void* sync, int* status, void* stream);
+                     void* dgf_bf16, void* sync, int* status, void* stream);
 
 /* ---- small data-movement / elementwise kernels ------------------------------------------------- */
 /* out[d1][d0][:] = in[d0][d1][:] (batch-major <-> time-major; replaces the implicit layout of batch_first) */

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import P, I, F, ptr, check, cur_stream
-from .decoder import DecDims, DecState, make_params, weight_names, LOC_C
+from .decoder import DecDims, DecState, make_params, weight_names, s_dtype, LOC_C
 
 CTC_BEAM_RATIO = 1.5          # asr.py:15
 
@@ -105,7 +105,7 @@ def beam_decode(model, audio_feature, decode_step, state_len, decode_beam_size):
                      logits_step=torch.empty(N, V, **f32))
             if loc:
                 S['f'] = torch.empty(1, N, LOC_C, Tp, **f32)
-                S['s'] = torch.empty(1, N, Tp, A, **f32)
+                S['s'] = torch.empty(1, N, Tp, A, dtype=s_dtype(d.prec), device=dev)
             st = DecState()
             for k, v in S.items():
                 setattr(st, k, v.data_ptr())

@@ -53,7 +53,7 @@ struct AttArgs {
     const float* conv_w; const float* w_lp; const float* w_e; const float* b_e;
     float* e;                 // [B][Tp]
     float* f;                 // [B][10][Tp]  (loc, saved)
-    float* s;                 // [B][Tp][A]   (loc, saved)
+    void* s; int s16;         // [B][Tp][A]   (loc, saved): fp32, or the 16-bit code of las_common.h (s16, bf16 mode)
 };
 
 // grid (NCH, B): energies of T'-chunk [t0, t0+TC) of utterance b.  8 waves per workgroup: a chunk's <= 20 frames
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(ATTF_NT) void att_energy_fwd(AttArgs a) {
         float acc = 0.f;
         const int tt = t - t0;
         if (t < len) {
-            float* __restrict__ so = a.s + ((long)b * a.Tp + t) * a.A;
+            const long so = ((long)b * a.Tp + t) * a.A;
             float fc[LOC_C];
 #pragma unroll
             for (int c = 0; c < LOC_C; ++c) fc[c] = f_l[c * a.TC + tt];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(ATTF_NT) void att_energy_fwd(AttArgs a) {
                     for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
                     u = fast_tanh(u);
                     const float sv = fast_tanh(pv[r][k] + q_l[i] + u);
-                    so[i] = sv;
+                    las_s_store(a.s, so + i, a.s16, sv);
                     acc += we_l[i] * sv;
                 }
             }
@@ -349,7 +349,8 @@ static int decoder_run(const las_dec_dims* d, const las_dec_params* p, const flo
         a.conv_w = p->conv_w; a.w_lp = p->w_lp; a.w_e = p->w_e; a.b_e = p->b_e;
         a.e = s.ebuf;
         a.f = loc ? s.f + (long)t * B * LOC_C * Tp : nullptr;
-        a.s = loc ? s.s + (long)t * B * Tp * A : nullptr;
+        a.s16 = prec == LAS_PREC_BF16;
+        a.s = loc ? (void*)((char*)s.s + (size_t)t * B * Tp * A * (a.s16 ? 2 : 4)) : nullptr;
         if (!loc) hipLaunchKernelGGL((att_energy_fwd<false, 1>), dim3(NCH, B), dim3(ATTF_NT), lds_e, st, a);
         else {
             const int AI = (A + 63) / 64;

@@ -56,7 +56,7 @@ struct AttBwdArgs {
     float* de;                // [B][Tp] d loss / d energy of this step (saved for the post-loop contractions)
     // loc
     const float* f;           // [B][10][Tp] location features of this step
-    const float* s;           // [B][Tp][A] tanh(psi + q + u)
+    const void* s; int s16;   // [B][Tp][A] tanh(psi + q + u): fp32, or the 16-bit code of las_common.h (s16, bf16 mode)
     const float* w_lp; const float* w_e; const float* conv_w;
     float* df;                // [B][10][Tp] d loss / d f of this step (caller-zeroed; frames < len written)
     const float* df_next;     // [B][10][Tp] d f of step t+1 (NULL at the last step): the location conv of step t+1
@@ -100,9 +100,11 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < ATT_ROWS; ++r) {
             const int t = min(t0 + wave + ATT_NW * r, a.Tp - 1);
-            const float* __restrict__ sp = a.s + ((long)b * a.Tp + t) * a.A;
 #pragma unroll
-            for (int k = 0; k < AI; ++k) svr[r][k] = sp[min(lane + 64 * k, a.A - 1)];
+            for (int k = 0; k < AI; ++k) {           // (only 1 - s^2 is needed here)
+                float s_;
+                las_s_load(a.s, ((long)b * a.Tp + t) * a.A + min(lane + 64 * k, a.A - 1), a.s16, s_, svr[r][k]);
+            }
         }
     }
     // ... and so are this wave's enc rows (<= EV float4 per lane and row: E <= 256 EV on this path; the 6 x 1024 pBLSTM of
@@ -287,8 +289,7 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < LOC_C; ++c) u += wlp_l[c * a.A + i] * fc[c];
                 u = fast_tanh(u);
-                const float sv = svr[r][k];
-                const float dz = de * we_l[i] * (1.f - sv * sv);
+                const float dz = de * we_l[i] * svr[r][k];
                 dq_r[k] += dz;
                 const float du = dz * (1.f - u * u);
 #pragma unroll
@@ -321,9 +322,9 @@ struct LocPostArgs {
     const int32_t* lens;
     const float* de;          // [L][B][Tp]
     const float* f;           // [L][B][10][Tp]
-    const float* s;           // [L][B][Tp][A]
+    const void* s; int s16;   // [L][B][Tp][A]: fp32, or the 16-bit code of las_common.h (s16, bf16 mode)
     const float* w_lp; const float* w_e;
-    float* dpsi;              // [B][Tp][A]   (caller-zeroed; rows < len written)
+    float* dpsi;              // [B][Tp][A]   (caller-zeroed; rows < len written); null: the BPTT loop has summed d psi itself
     float* acc;               // [B][acc_stride]: d w_lp^T [10][A] | d w_e [A] | d b_e [1] | pad | d conv [10*201]  (+=)
     long acc_stride;
 };
@@ -364,12 +365,12 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
         auxp[q] = (j == 0 ? a.de + (long)b * a.Tp : a.f + ((long)b * LOC_C + (j - 1)) * a.Tp) + min(t0 + ra, t0 + tcv - 1);
         aux_step[q] = j == 0 ? step_e : step_f;
     }
-    const float* __restrict__ sp0 = a.s + (long)b * a.Tp * a.A + ic;
     auto load = [&](float (&sv)[POST_TC], float (&aux)[POST_NAUX], int l) {
 #pragma unroll
         for (int r = 0; r < POST_TC; ++r) {
             const int t = min(t0 + r, t0 + tcv - 1);
-            sv[r] = sp0[l * step_s + (long)t * a.A];
+            const long si = l * step_s + ((long)b * a.Tp + t) * a.A + ic;
+            sv[r] = a.s16 ? __uint_as_float((unsigned)((const bf16_t*)a.s)[si]) : ((const float*)a.s)[si];      // (raw: decoded where used)
         }
 #pragma unroll
         for (int q = 0; q < POST_NAUX; ++q) aux[q] = auxp[q][l * aux_step[q]];
@@ -390,8 +391,9 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
                 u += wlp_r[c] * fc[c];
             }
             u = fast_tanh(u);
-            const float s_ = sv[r];
-            const float dz = de * we_r * (1.f - s_ * s_);
+            float s_ = sv[r], ds_ = 1.f - s_ * s_;
+            if (a.s16) { const unsigned x = __float_as_uint(sv[r]); s_ = las_s16_s(x); ds_ = las_s16_ds(x); }
+            const float dz = de * we_r * ds_;
             dps[r] += dz;
             dwe_r += de * s_;
             const float du = dz * (1.f - u * u);
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(512) void att_loc_post(LocPostArgs a) {
     if (i < a.A) {
 #pragma unroll
         for (int r = 0; r < POST_TC; ++r)
-            if (r < tcv) a.dpsi[((long)b * a.Tp + t0 + r) * a.A + i] = dps[r];
+            if (r < tcv && a.dpsi) a.dpsi[((long)b * a.Tp + t0 + r) * a.A + i] = dps[r];
         float* accg = a.acc + (long)b * a.acc_stride;
         atomicAdd(&accg[a.A * LOC_C + i], dwe_r);
 #pragma unroll
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
         const int acol = (wave + NW * i) * 16 + fr;
         okc[i] = acol < A;
         const int ac = min(acol, A - 1);
-        corr[i] = (ac - acol) * 4;
+        corr[i] = (min(acol & ~1, A - 2) - (acol & ~1)) * 2;      // (of my column PAIR: A is even on this path)
         we_r[i] = okc[i] ? a.w_e[ac] : 0.f;
         float w[4];
 #pragma unroll
@@ -458,7 +460,14 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
         wlpB[i] = bf16x4{(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
     }
     bool tv[4];
-    int voff_s[4], off_fu[4];                           // byte offsets inside the step's slab of utterance b
+    int voff_s[2], off_fu[4];                           // byte offsets inside the step's slab of utterance b
+    // s (the 16-bit code) is read as 32-bit words = column pairs: an even lane takes the pair (fr, fr + 1) of rows 0 and 2, its odd
+    // neighbour the same pair of rows 1 and 3, and the two swap over DPP -- 2 loads per tile instead of 4 two-byte ones
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int tc = min(t0 + 4 * g + 2 * k + (fr & 1), len - 1);
+        voff_s[k] = (tc * A + wave * 16 + (fr & ~1)) * 2;      // tile i: + i * NW * 32 bytes (wave-uniform: the scalar offset)
+    }
     bool v_fu[4], v_fw[4];
     // de and the d W_lp operand are four CONSECUTIVE frames: one 16-byte load each (frames beyond the utterance are
     // masked, beyond the slab the buffer returns zero)
@@ -467,8 +476,6 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
     for (int r = 0; r < 4; ++r) {
         const int t = t0 + 4 * g + r;
         tv[r] = t < len;
-        const int tc = min(t, len - 1);
-        voff_s[r] = (tc * A + wave * 16 + fr) * 4;      // tile i: + i * NW * 64 bytes (wave-uniform: the scalar offset)
         // u operand: lane (m = frame t0 + fr, k = channel 4g + r)
         const int c = 4 * g + r, tf = t0 + fr;
         v_fu[r] = c < LOC_C && tf < len;
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
         v_fw[r] = fr < LOC_C && tv[r];
     }
     const long step_s = (long)a.B * Tp * A, step_f = (long)a.B * LOC_C * Tp, step_e = (long)a.B * Tp;
-    const float* __restrict__ sb = a.s + (long)b * Tp * A;
+    const bf16_t* __restrict__ sb = (const bf16_t*)a.s + (long)b * Tp * A;
     const float* __restrict__ fb = a.f + (long)b * LOC_C * Tp;
     const float* __restrict__ eb = a.de + (long)b * Tp;
     const int nt_w = (ntiles - wave + NW - 1) / NW;           // tiles this wave really has (wave-uniform)
@@ -485,17 +492,17 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
     // One buffer resource per step and tensor (scalar work), 32-bit lane offsets: the 4*NT loads of a step share four
     // offset registers.  Every s element a lane reads is a DEFINED one (rows clamped to the utterance's last frame, columns
     // to A - 1), so s needs no select: the masked de / w_e make its terms exact zeros.
-    struct Set { float s[NT][4]; float de[4], fu[4], fw[4]; };
+    struct Set { float s[NT][2]; float de[4], fu[4], fw[4]; };
     auto load = [&](Set& q, int l) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sb + l * step_s), 0, Tp * A * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sb + l * step_s), 0, Tp * A * 2, 0x00020000);
         __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + l * step_f), 0, LOC_C * Tp * 4, 0x00020000);
         __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void*)(eb + l * step_e), 0, Tp * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
             if (i < nt_w) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    q.s[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff_s[r] + corr[i], i * NW * 64, 0));
+                for (int k = 0; k < 2; ++k)
+                    q.s[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff_s[k] + corr[i], i * NW * 32, 0));      // (raw codes of a column pair)
             }
         const u32x4 ve = __builtin_amdgcn_raw_buffer_load_b128(re, off_e, 0, 0);
         const u32x4 vw = __builtin_amdgcn_raw_buffer_load_b128(rf, off_fw, 0, 0);
@@ -530,11 +537,17 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
             if (i < nt_w) {
                 const f32x4 u = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fu, wlpB[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 float du[4];
+                // my words (rows 0, 2 | 1, 3) and my neighbour's (rows 1, 3 | 0, 2); my column is the low (even lane) or high half
+                const unsigned w0 = __float_as_uint(q.s[i][0]), w1 = __float_as_uint(q.s[i][1]);
+                const unsigned p0 = __float_as_uint(las_dpp<0xB1, 0xf>(0.f, q.s[i][0])), p1 = __float_as_uint(las_dpp<0xB1, 0xf>(0.f, q.s[i][1]));
+                const bool odd = fr & 1;
+                const unsigned rw[4] = {odd ? p0 : w0, odd ? w0 : p0, odd ? p1 : w1, odd ? w1 : p1};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float s_ = q.s[i][r];
+                    const unsigned sx = odd ? rw[r] >> 16 : rw[r] & 0xffffu;
+                    const float s_ = las_s16_s(sx);
                     const float th = fast_tanh(u[r]);          // (rows beyond the utterance: F = 0 there, u = 0)
-                    const float dz = de[r] * we_r[i] * (1.f - s_ * s_);
+                    const float dz = de[r] * we_r[i] * las_s16_ds(sx);
                     dps[i][r] += dz;
                     dwe[i] = fmaf(de[r], s_, dwe[i]);
                     du[r] = dz * (1.f - th * th);
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
             const int acol = (wave + NW * i) * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (okc[i] && tv[r]) atomicAdd(&a.dpsi[((long)b * Tp + t0 + 4 * g + r) * A + acol], dps[i][r]);
+                if (okc[i] && tv[r] && a.dpsi) atomicAdd(&a.dpsi[((long)b * Tp + t0 + 4 * g + r) * A + acol], dps[i][r]);
             float v = dwe[i];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
@@ -678,6 +691,7 @@ int att_chunks(int Tp) { const int n = (Tp + 19) / 20; return n < 1 ? 1 : n; }
 
 extern "C" int64_t las_decoder_loc_acc_floats(int A) { return ((A * LOC_C + A + 1 + 3) / 4) * 4 + LOC_C * LOC_W; }
 extern "C" int las_decoder_att_chunks(int Tp) { return att_chunks(Tp); }
+extern "C" size_t las_decoder_s_elem_bytes(int prec) { return prec == LAS_PREC_BF16 ? 2 : 4; }
 extern "C" size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* d) { return las_dec_pk_bwd_ws_bytes(d); }
 
 static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const float* enc, const float* psi,
@@ -791,7 +805,8 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
         a.de = w.de + (long)t * B * Tp;
         if (loc) {
             a.f = s.f + (long)t * B * LOC_C * Tp;
-            a.s = s.s + (long)t * B * Tp * A;
+            a.s16 = prec == LAS_PREC_BF16;
+            a.s = (const char*)s.s + (size_t)t * B * Tp * A * (a.s16 ? 2 : 4);
             a.w_lp = p->w_lp; a.w_e = p->w_e; a.conv_w = p->conv_w;
             a.df = w.df + (long)t * B * LOC_C * Tp;
             if (t + 1 < L) {
@@ -831,12 +846,14 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     }
     if (loc && chain) {
         // ---- sums over the L steps that are off the sequential chain; d psi is the one the encoder's backward waits for
+        // (summing d psi inside the persistent loop instead was measured at c3: as float atomics at the L2 the step grew from
+        // 16.1 to 17.2 ms, as a read-modify-write pass at the end of every step to 18.4 ms -- the attention role has no slack)
         LocPostArgs q{};
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
-        q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride;
+        q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride; q.s16 = prec == LAS_PREC_BF16;
         const int no_mma = las_fallback("LAS_LOC_POST_VALU") ? 1 : 0;         // (tests compare the two kernels; read per call)
-        if (prec == LAS_PREC_BF16 && !no_mma) {
+        if (prec == LAS_PREC_BF16 && !no_mma && (A & 1) == 0) {       // (the MFMA kernel reads s as column pairs)
             const int ntiles = (A + 15) / 16, NW = ntiles <= 20 ? 4 : 8, NT = (ntiles + NW - 1) / NW;
             const dim3 grid((Tp + 15) / 16, B, L >= 48 ? 3 : 1), blk(64 * NW);
             switch (NT) {

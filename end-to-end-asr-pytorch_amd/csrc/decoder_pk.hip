@@ -62,7 +62,7 @@ struct PkArgs {
     const float* xe;                    // [L][B][4C] W_ih[:, 0:C] emb_t + b_ih
     const float* w_ih; const float* w_hh; const float* b_hh; const float* w_phi;
     const float* conv_w; const float* w_lp; const float* w_e; const float* b_e;
-    float* q; float* att; float* xin; float* hs; float* cs; float* gates; float* f; float* s;
+    float* q; float* att; float* xin; float* hs; float* cs; float* gates; float* f; void* s;      // (s: fp32, or the 16-bit code of las_common.h in bf16 mode)
     u32x4 *hxg, *cxg, *qxg, *exg;       // granule rings [2][B][HG], [2][B][NCH*CG], [2][B][QG], [2][B][NCH*TCG]
     PkSync* sync; int* status;
     unsigned long long* dbg;            // [grid][12] cycle sums per phase (stamps build only)
@@ -604,11 +604,14 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
             for (int r = 0; r < 4; ++r) {
                 const int tt = mt * 16 + fq * 4 + r, tp = r0 + tt;
                 if (tt < TCr && tp < len) {
-                    float* __restrict__ so = a.s + (((long)t * B + b) * Tp + tp) * A;
+                    const long so = (((long)t * B + b) * Tp + tp) * A;
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
                         const int aa = (wave + PNW * j) * 16 + fr;
-                        if (aa < A) __builtin_nontemporal_store(uv[mt][j][r], &so[aa]);
+                        if (aa < A) {
+                            if constexpr (PREC == LAS_PREC_BF16) __builtin_nontemporal_store(las_s16_enc(uv[mt][j][r]), (bf16_t*)a.s + so + aa);
+                            else __builtin_nontemporal_store(uv[mt][j][r], (float*)a.s + so + aa);
+                        }
                     }
                 }
             }

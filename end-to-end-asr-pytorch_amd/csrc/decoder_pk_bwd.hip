@@ -58,7 +58,7 @@ struct PbArgs {
     const float* enc; const float* psi; const int32_t* lens;
     const float* w_ih; const float* w_hh; const float* w_phi; const float* conv_w; const float* w_lp; const float* w_e;
     // saved by the forward loop
-    const float* att; const float* q; const float* gates; const float* cs; const float* f; const float* s;
+    const float* att; const float* q; const float* gates; const float* cs; const float* f; const void* s;      // (s: fp32, or the 16-bit code of las_common.h in bf16 mode)
     const float* g_htop;
     // outputs (las_dec_bwd_state)
     float* dgates; float* dxin; float* dq_pre; float* de; float* df;
@@ -387,9 +387,13 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tp = min(r0 + mt * 16 + fq * 4 + r, Tp - 1);
-                const float* __restrict__ sp = a.s + (((long)t_ * B + b) * Tp + tp) * A;
+                const long so = (((long)t_ * B + b) * Tp + tp) * A;
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) sv[mt][j][r] = sp[min((wave + PNW * j) * 16 + fr, A - 1)];
+                for (int j = 0; j < NTW; ++j) {            // bf16 mode: sv = 1 - |s| (all phase E needs: 1 - s^2 = sv (2 - sv))
+                    const int aa = min((wave + PNW * j) * 16 + fr, A - 1);
+                    if constexpr (PREC == LAS_PREC_BF16) sv[mt][j][r] = las_s16_t(((const bf16_t*)a.s)[so + aa]);
+                    else sv[mt][j][r] = ((const float*)a.s)[so + aa];
+                }
             }
     };
     float pf_att[2] = {0.f, 0.f}, pf_f = 0.f, pf_q = 0.f;
@@ -624,7 +628,8 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
                     // (frames beyond the utterance: the saved s is undefined there -- the forward loop never writes it --, and 0 * NaN
                     // would poison d q, d f and every gradient behind them; a select, not a product with d e = 0)
                     const float s_ = sv[mt][j][r];
-                    const float dz = tt < tcv ? (LOC ? de * wev[j] * (1.f - s_ * s_) : de * s_) : 0.f;      // (dot: s_ holds psi)
+                    const float ds_ = PREC == LAS_PREC_BF16 ? s_ * (2.f - s_) : 1.f - s_ * s_;
+                    const float dz = tt < tcv ? (LOC ? de * wev[j] * ds_ : de * s_) : 0.f;      // (dot: s_ holds psi)
                     dq[j] += dz;
                     if (!LOC) continue;
                     const int aa = (wave + PNW * j) * 16 + fr;

@@ -114,6 +114,27 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     const __bf16 h = (__bf16)f;
     return __builtin_bit_cast(unsigned short, h);
 }
+// ---- the saved s = tanh(psi + q + u) of the location-aware energies (asr.py:453), bf16 mode: 16 bits per element instead of
+// fp32 (s is the largest thing the decoder saves: L*B*T'*A elements, written once, read by the BPTT loop and by the sums
+// behind it).  The code is x = copysign(1 - |s|, s) as bf16 (RNE), not bf16(s): the backward pass needs
+//   1 - s^2 = t (2 - t), t = |x|   relative error 2^-8 -- also where tanh saturates, which bf16(s) would round to 0 or 2^-8
+//   s = sign(x) (1 - t)            absolute error <= 2^-9 (1 - |s|)      (d w_e += d e * s)
+// fp32 mode keeps plain fp32 s.  las_decoder_s_elem_bytes(prec) is the element size callers allocate with.
+__device__ __forceinline__ bf16_t las_s16_enc(float s) { return f2bf(copysignf(1.f - fabsf(s), s)); }
+__device__ __forceinline__ float las_s16_t(unsigned x) { return __uint_as_float((x & 0x7fffu) << 16); }
+__device__ __forceinline__ float las_s16_ds(unsigned x) { const float t = las_s16_t(x); return t * (2.f - t); }
+__device__ __forceinline__ float las_s16_s(unsigned x) {
+    return __uint_as_float(__float_as_uint(1.f - las_s16_t(x)) | ((x & 0x8000u) << 16));
+}
+// element i of a saved-s array in either format -> s and 1 - s^2
+__device__ __forceinline__ void las_s_load(const void* base, long i, int s16, float& s, float& ds) {
+    if (s16) { const unsigned x = ((const bf16_t*)base)[i]; s = las_s16_s(x); ds = las_s16_ds(x); }
+    else { s = ((const float*)base)[i]; ds = 1.f - s * s; }
+}
+__device__ __forceinline__ void las_s_store(void* base, long i, int s16, float s) {
+    if (s16) ((bf16_t*)base)[i] = las_s16_enc(s);
+    else ((float*)base)[i] = s;
+}
 typedef __attribute__((ext_vector_type(2))) float las_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 las_bf16x2;
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {       // one v_cvt_pk_bf16_f32

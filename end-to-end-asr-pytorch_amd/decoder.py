@@ -70,6 +70,11 @@ def make_params(W, NL, loc, transposed=None, packed=None):
     return p
 
 
+def s_dtype(prec):
+    """Element type of the saved s = tanh(psi + q + u): fp32, or the library's 16-bit code in bf16 mode (las_decoder_s_elem_bytes)."""
+    return {4: torch.float32, 2: torch.int16}[_lib.lib().las_decoder_s_elem_bytes(I(prec))]
+
+
 def alloc_state(dims, dev, status=None, persistent=True):
     """Saved-state tensors of one decode loop.  persistent: also the workspace of the one-launch loop (decoder_pk.hip) when
     the shape / mode is eligible (las_decoder_pk_workspace_bytes > 0); status: int32 [1] device tensor that a hand-off
@@ -89,7 +94,7 @@ def alloc_state(dims, dev, status=None, persistent=True):
     )
     if d.loc:
         S['f'] = torch.empty(d.L, d.B, LOC_C, d.Tp, **f32)
-        S['s'] = torch.empty(d.L, d.B, d.Tp, d.A, **f32)
+        S['s'] = torch.empty(d.L, d.B, d.Tp, d.A, dtype=s_dtype(d.prec), device=dev)
     if d.dropout > 0:
         S['xdrop'] = torch.empty(d.L, d.B, d.C + d.E, **f32)
         if d.NL > 1:

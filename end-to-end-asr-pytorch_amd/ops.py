@@ -533,7 +533,7 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     gates = torch.empty(T, B, ND * H4, dtype=torch.float32, device=dev)
     cs = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     # y's bf16 twin (operand of the projection GEMM behind the layer): written by the recurrence kernel itself, no cast pass
-    y16 = torch.empty(y.shape, dtype=torch.bfloat16, device=dev) if twins_on() and y.numel() >= TWIN_MIN_ELEMS and not os.environ.get('LAS_NO_KTWIN') else None
+    y16 = torch.empty(y.shape, dtype=torch.bfloat16, device=dev) if twins_on() and y.numel() >= TWIN_MIN_ELEMS else None
     kname = ('lstm_fwd_kernel', 'lstm_fwd_gr_kernel', 'lstm_fwd_x32_kernel')[L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND))]
     with _Timed(kname, 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
         check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
@@ -558,7 +558,7 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
     sync, dgx = sx[:nsync], sx[nsync:]              # (one allocation, the workspace behind the sync words: one zero fill)
     dgf = torch.empty(T * B, ND * H4, dtype=torch.float32, device=dev)
     # d gates' bf16 twin (operand of the d x / d W_ih / d W_hh GEMMs): written by the BPTT kernel itself, no cast pass
-    dgf16 = torch.empty(dgf.shape, dtype=torch.bfloat16, device=dev) if prec == 0 and USE_BF16_TWINS and dgf.numel() >= TWIN_MIN_ELEMS and not os.environ.get('LAS_NO_KTWIN') else None
+    dgf16 = torch.empty(dgf.shape, dtype=torch.bfloat16, device=dev) if prec == 0 and USE_BF16_TWINS and dgf.numel() >= TWIN_MIN_ELEMS else None
     ksplit = L_.las_lstm_bwd_is_ksplit(I(prec), I(T), I(B), I(H), I(ND))
     if _ldist._ACTIVE['ex'] is not None:        # gradient buckets in flight on RCCL's stream: do they and this launch both fit?
         _ldist.persistent_launch_guard(L_.las_lstm_resident_wgs(I(prec), I(T), I(B), I(H), I(ND)), dev)

@@ -169,7 +169,8 @@ typedef struct {                    /* saved activations, written by fwd, read b
     float* cs;                      /* [NL][L+1][B][C] */
     float* gates;                   /* [NL][L][B][4C] post-activation */
     float* f;                       /* loc: [L][B][10][Tp] location features */
-    float* s;                       /* loc: [L][B][Tp][A] tanh(psi + q + u) */
+    void* s;                        /* loc: [L][B][Tp][A] tanh(psi + q + u): fp32 in LAS_PREC_F32; in LAS_PREC_BF16 a 16-bit code per
+                                     * element (bf16 of copysign(1 - |s|, s): las_common.h), las_decoder_s_elem_bytes() bytes each */
     float* ebuf;                    /* [B][Tp] scratch */
     float* logits_step;             /* [B][V] scratch (sampled / greedy steps) */
     float* xdrop;                   /* dropout > 0: [L][B][C+E] cell-0 input after dropout (xin keeps the clean one) */
@@ -213,6 +214,7 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
 size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* dims);
 int64_t las_decoder_loc_acc_floats(int A);
 int las_decoder_att_chunks(int Tp);
+size_t las_decoder_s_elem_bytes(int prec);          /* element size of las_dec_state.s: 4 (fp32) | 2 (LAS_PREC_BF16: the 16-bit code) */
 /* g_htop [L][B][C]: gradient wrt the top-layer hidden state of every step (from char_trans).  After this call
  * the remaining sums over steps are plain contractions for las_gemm / las_colsum:
  *   dW_ih[l] = dgates[l]^T x_l, dW_hh[l] = dgates[l]^T hs[l][0:L], db = colsum(dgates[l]), dW_phi = dq_pre^T hs[0][0:L],

@@ -597,24 +597,50 @@ __device__ __forceinline__ void pk_att_role(const PkArgs& a, char* smem) {
         }
         // s = tanh(psi + q + u) of my frames, saved for the backward pass: stored only now, after both hand-offs of the
         // step, so that neither waits for these stores (write-only stream: non-temporal)
-        if (LOC)
+        if (LOC) {
+            if constexpr (PREC == LAS_PREC_BF16) {          // (pk_geom: A is even then)
+                // the 16-bit code, two columns per store: an even lane writes the pair (fr, fr + 1) of rows 0 and 2, its odd neighbour
+                // the same pair of rows 1 and 3 (codes swapped over DPP) -- 18 four-byte stores per lane instead of 36 two-byte ones
+                const bool odd = fr & 1;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tt = mt * 16 + fq * 4 + r, tp = r0 + tt;
-                if (tt < TCr && tp < len) {
-                    const long so = (((long)t * B + b) * Tp + tp) * A;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
-                        const int aa = (wave + PNW * j) * 16 + fr;
-                        if (aa < A) {
-                            if constexpr (PREC == LAS_PREC_BF16) __builtin_nontemporal_store(las_s16_enc(uv[mt][j][r]), (bf16_t*)a.s + so + aa);
-                            else __builtin_nontemporal_store(uv[mt][j][r], (float*)a.s + so + aa);
+                        const int aa = (wave + PNW * j) * 16 + (fr & ~1);
+                        unsigned c[4], n[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            c[r] = las_s16_enc(uv[mt][j][r]);
+                            n[r] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c[r], 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int tt = mt * 16 + fq * 4 + 2 * k + (odd ? 1 : 0), tp = r0 + tt;
+                            const unsigned w = odd ? (n[2 * k + 1] | (c[2 * k + 1] << 16)) : (c[2 * k] | (n[2 * k] << 16));      // (static indices: registers)
+                            if (tt < TCr && tp < len && aa < A)
+                                __builtin_nontemporal_store(w, (unsigned*)((bf16_t*)a.s + (((long)t * B + b) * Tp + tp) * A + aa));
                         }
                     }
-                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tt = mt * 16 + fq * 4 + r, tp = r0 + tt;
+                        if (tt < TCr && tp < len) {
+                            const long so = (((long)t * B + b) * Tp + tp) * A;
+#pragma unroll
+                            for (int j = 0; j < NTW; ++j) {
+                                const int aa = (wave + PNW * j) * 16 + fr;
+                                if (aa < A) {
+                                    if constexpr (PREC == LAS_PREC_BF16) __builtin_nontemporal_store(las_s16_enc(uv[mt][j][r]), (bf16_t*)a.s + so + aa);
+                                    else __builtin_nontemporal_store(uv[mt][j][r], (float*)a.s + so + aa);
+                                }
+                            }
+                        }
+                    }
             }
+        }
         PK_STAMP(8);
     }
     PK_STAMP_FLUSH(a.dbg);
@@ -647,6 +673,7 @@ bool pk_geom(const las_dec_dims* d, PkGeom& best) {
     if (!d || d->NL != 1 || d->dropout != 0.f || d->L < 1) return false;      // (dot and location-aware attention)
     if (d->B < 1 || d->B > MAXB || d->A > 512 || d->A < 1 || d->Tp < 1 || (d->C & 1)) return false;
     if (d->prec != LAS_PREC_BF16 && d->prec != LAS_PREC_F32) return false;
+    if (d->prec == LAS_PREC_BF16 && d->loc && (d->A & 1)) return false;       // (the saved s is written as column pairs)
     if (las_fallback("LAS_DEC_NO_PK")) return false;
     const int ks = d->prec == LAS_PREC_BF16 ? 32 : 16, vec = d->prec == LAS_PREC_BF16 ? 8 : 4;
     int want_ns = 0, want_u = 0;

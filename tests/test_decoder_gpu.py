@@ -323,6 +323,47 @@ def test_persistent_bptt_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L)
         assert np.abs(got - ref).max() <= lim, (k, float(np.abs(got - ref).max()), float(lim))
 
 
+def test_odd_attention_dim_bf16_keeps_the_per_step_kernels(mods):
+    """bf16 mode saves s = tanh(psi + q + u) as a 16-bit code that the persistent loops and the MFMA post-loop sums access as
+    column PAIRS: an odd attention dim keeps the per-step kernels (2-byte accesses) and the VALU post-loop sums.  Their
+    gradients against the same loop in fp32 mode: 3e-2 of the largest entry (bf16 operands)."""
+    ops, dec = mods
+    B, Tp, E, A, C, V, L = 5, 60, 48, 37, 32, 31, 6
+    rng = np.random.RandomState(77)
+    W = rand_weights(rng, V, C, E, A, 1, True)
+    lens = sorted(rng.randint(Tp // 2, Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    names = dec.weight_names(1, True)
+    res = {}
+    try:
+        for prec in ('f32', 'bf16'):
+            ops.set_precision(prec)
+            Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+            enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+            psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+            h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                             torch.tensor(y, device=DEV), L, 1, True, None, 0, *[Wg[k] for k in names])
+            (h_top * torch.tensor(G, device=DEV)).sum().backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            if prec == 'bf16':
+                assert dec.DecoderFn.last_pk_bwd_ws is None, 'an odd attention dim was meant to keep the per-step kernels in bf16 mode'
+            res[prec] = dict({'h_top': h_top.detach().cpu().numpy(), 'd enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
+                             **{k: Wg[k].grad.cpu().numpy() for k in names if not k.startswith('char_trans')})
+    finally:
+        ops.set_precision('bf16')
+    for k, ref in res['f32'].items():
+        if k == 'attention.gen_energy.bias':
+            continue                    # (cancels to rounding noise)
+        err = np.abs(res['bf16'][k] - ref).max()
+        assert err <= 3e-2 * np.abs(ref).max() + 1e-6, (k, float(err), float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize('B,Tp,E,A,C,V,L', [(5, 150, 48, 40, 32, 31, 6),        # one tile per wave, no step split
                                             (4, 40, 32, 512, 32, 17, 5),        # A = 512: eight waves, four tiles each
                                             (6, 77, 64, 130, 64, 17, 50),       # steps shared by three workgroups per tile

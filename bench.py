@@ -247,6 +247,11 @@ def main():
         torch.cuda.synchronize()
 
     note(f'model built ({t.asr_model.n_params} params), {n_stage} batches staged; warmup {a.warmup}')
+    # the step's dependency chain runs on a high-priority stream, as in Trainer.exec: where a side stream's kernel and the
+    # chain's next kernel are both ready, the chain's goes first
+    ms = ops.main_stream()
+    ms.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(ms)
     run(0, a.warmup)
     barrier()
     note(f'timing {a.steps} steps')

@@ -616,6 +616,65 @@ __global__ __launch_bounds__(512) void att_loc_post_mma(LocPostArgs a, int NW) {
     }
 }
 
+// d psi alone, bf16 mode behind the persistent loops (coded s, even A): the one post-loop sum the encoder's backward waits for
+// needs only s, d e and w_e -- d psi[b,t,a] = w_e[a] * sum_l d e_l[b,t] (1 - s_l[b,t,a]^2) -- so it is a pure stream over the saved
+// s (2 bytes per element) on the caller's main stream, and att_loc_post_mma's MFMA work (d W_lp, d w_e, d b_e: parameter
+// gradients) moves to the parameter sums beside it.  Workgroup = (utterance, DPS_FT frames): per step its s values are ONE
+// contiguous run of DPS_FT * A codes, read as 32-bit words (column pairs), K words per thread; plain stores (a thread owns its
+// elements), steps behind the block's last nonzero d e are skipped (ragged label lengths).
+constexpr int DPS_FT = 8, DPS_NT = 256;
+template <int K>
+__global__ __launch_bounds__(DPS_NT) void att_dpsi_kernel(LocPostArgs a) {
+    __shared__ int lmax_s;
+    const int b = blockIdx.y, t0 = blockIdx.x * DPS_FT, len = a.lens[b];
+    if (t0 >= len) return;
+    const int A = a.A, Tp = a.Tp, nf = min(DPS_FT, len - t0), nw = nf * A / 2, tid = threadIdx.x;
+    const long step_e = (long)a.B * Tp, step_w = (long)a.B * Tp * A / 2;
+    const float* __restrict__ dep = a.de + (long)b * Tp + t0;
+    if (tid == 0) lmax_s = -1;
+    __syncthreads();
+    {
+        int lm = -1;
+        for (int l = tid; l < a.L; l += DPS_NT) {
+            bool nz = false;
+            for (int f = 0; f < nf; ++f) nz |= dep[l * step_e + f] != 0.f;
+            if (nz) lm = l;
+        }
+        if (lm >= 0) atomicMax(&lmax_s, lm);
+    }
+    __syncthreads();
+    const int L = lmax_s + 1;
+    const unsigned* __restrict__ sp = (const unsigned*)((const bf16_t*)a.s + ((long)b * Tp + t0) * A);
+    float we0[K], we1[K], acc0[K], acc1[K];
+    int fo[K], wo[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int w = tid + DPS_NT * k, wc = min(w, nw - 1), e = 2 * wc, f = e / A, c = e - f * A;      // (A even: a pair never straddles two rows)
+        const bool ok = w < nw;
+        wo[k] = wc; fo[k] = f;
+        we0[k] = ok ? a.w_e[c] : 0.f; we1[k] = ok ? a.w_e[c + 1] : 0.f;
+        acc0[k] = 0.f; acc1[k] = 0.f;
+    }
+#pragma unroll 2
+    for (int l = 0; l < L; ++l) {
+        unsigned x[K];
+        float de[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { x[k] = __builtin_nontemporal_load(sp + l * step_w + wo[k]); de[k] = dep[l * step_e + fo[k]]; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            acc0[k] = fmaf(de[k], las_s16_ds(x[k] & 0xffffu), acc0[k]);
+            acc1[k] = fmaf(de[k], las_s16_ds(x[k] >> 16), acc1[k]);
+        }
+    }
+    float* __restrict__ out = a.dpsi + ((long)b * Tp + t0) * A;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int w = tid + DPS_NT * k;
+        if (w < nw) *(float2*)(out + 2 * w) = make_float2(acc0[k] * we0[k], acc1[k] * we1[k]);
+    }
+}
+
 // d conv_w[c][k] += sum over this block's (step, utterance) pairs of  sum_t df[c][t] * prev[t + k - K].
 // Thread = (c, 10 consecutive k): a sliding register window over prev gives 10 FMAs per two LDS reads.
 constexpr int CW_KPT = 10, CW_GROUPS = (LOC_W + CW_KPT - 1) / CW_KPT;       // 21 groups x 10 channels = 210 threads
@@ -844,14 +903,29 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
             if (rc) return rc;
         }
     }
-    if (loc && chain) {
-        // ---- sums over the L steps that are off the sequential chain; d psi is the one the encoder's backward waits for
-        // (summing d psi inside the persistent loop instead was measured at c3: as float atomics at the L2 the step grew from
-        // 16.1 to 17.2 ms, as a read-modify-write pass at the end of every step to 18.4 ms -- the attention role has no slack)
+    // ---- sums over the L steps that are off the sequential chain.  d psi is the one the encoder's backward waits for; behind the
+    // persistent loops in bf16 mode (coded s, even A) it is a stream of its own on the caller's main stream (att_dpsi_kernel) and
+    // the MFMA pass over s / f / d e is left with parameter gradients, which run with the other parameter sums; otherwise one pass
+    // makes both.  (Summing d psi inside the persistent loop instead was measured at c3: as float atomics at the L2 the loop grew by
+    // 5 us a step, as a read-modify-write pass at the end of every step by 9 us -- the attention role has no slack.)
+    const bool split_post = loc && pk && prec == LAS_PREC_BF16 && (A & 1) == 0 && A <= 512 && !las_fallback("LAS_LOC_POST_VALU");
+    if (split_post && chain) {
+        LocPostArgs q{};
+        q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
+        q.de = w.de; q.s = s.s; q.s16 = 1; q.w_e = p->w_e; q.dpsi = w.dpsi;
+        const dim3 grid((Tp + DPS_FT - 1) / DPS_FT, B);
+        const int K = (DPS_FT * A / 2 + DPS_NT - 1) / DPS_NT;
+        if (K <= 2) hipLaunchKernelGGL(att_dpsi_kernel<2>, grid, dim3(DPS_NT), 0, st, q);
+        else if (K <= 4) hipLaunchKernelGGL(att_dpsi_kernel<4>, grid, dim3(DPS_NT), 0, st, q);
+        else if (K <= 6) hipLaunchKernelGGL(att_dpsi_kernel<6>, grid, dim3(DPS_NT), 0, st, q);
+        else hipLaunchKernelGGL(att_dpsi_kernel<8>, grid, dim3(DPS_NT), 0, st, q);
+        LAS_LAUNCH_OK();
+    }
+    if (loc && (split_post ? sums : chain)) {
         LocPostArgs q{};
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;
         q.de = w.de; q.f = s.f; q.s = s.s; q.w_lp = p->w_lp; q.w_e = p->w_e;
-        q.dpsi = w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride; q.s16 = prec == LAS_PREC_BF16;
+        q.dpsi = split_post ? nullptr : w.dpsi; q.acc = w.acc; q.acc_stride = acc_stride; q.s16 = prec == LAS_PREC_BF16;
         const int no_mma = las_fallback("LAS_LOC_POST_VALU") ? 1 : 0;         // (tests compare the two kernels; read per call)
         if (prec == LAS_PREC_BF16 && !no_mma && (A & 1) == 0) {       // (the MFMA kernel reads s as column pairs)
             const int ntiles = (A + 15) / 16, NW = ntiles <= 20 ? 4 : 8, NT = (ntiles + NW - 1) / NW;

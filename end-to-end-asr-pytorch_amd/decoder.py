@@ -268,7 +268,7 @@ class DecoderFn(torch.autograd.Function):
                     red = ops.colsum(Bw['acc'], torch.empty(accf, **f32))
                     for n, v in loc_grads(red).items():
                         tg[n].add_(v)
-            ops.on_side_stream(param_sums, [Bw['demb'], Bw['dxin'], Bw.get('df'), Bw.get('acc'), S['att'], S['tok'], enc_len, g_htop],
+            ops.on_side_stream(param_sums, [Bw['demb'], Bw['dxin'], Bw.get('df'), Bw.get('acc'), Bw['de'], S['att'], S['tok'], S.get('s'), S.get('f'), enc_len, g_htop],
                                which=1)
         else:
             g['embed.weight'] = Bw['demb']

@@ -197,6 +197,16 @@ class Trainer(Solver):
 
     def exec(self):
         self.verbose('Training set total ' + str(len(self.train_set)) + ' batches.')
+        if self.device.type == 'cuda':                   # the dependency chain on a high-priority stream (ops.main_stream)
+            ms = ops.main_stream()
+            ms.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ms):
+                self._exec()
+            torch.cuda.current_stream().wait_stream(ms)
+        else:
+            self._exec()
+
+    def _exec(self):
         self.asr_opt.zero_grad()
         while self.step < self.max_step:
             for x, y in self.train_set:

@@ -314,6 +314,7 @@ class Seq2Seq(nn.Module):
                 mode = [1] + [2] * (L - 1)
                 y = None
             step_mode = None if all(m == 1 for m in mode) and y is not None else mode
+            ops.twin(enc, make=True)          # enc's bf16 copy, attached to enc: the psi GEMM and the per-step attention backward read it
             psi = ops.linear(enc, self.P('attention.psi.weight'), self.P('attention.psi.bias'), act=1)
             loc = self.att_mode == 'loc'
             ws = [self.P(n) for n in weight_names(self.dec_layers, loc)]

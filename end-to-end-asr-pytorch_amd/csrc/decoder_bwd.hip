@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void cell_pw_bwd(int B, int C, const float* __
 struct AttBwdArgs {
     int B, Tp, E, A, TC, NCH;
     const float* enc;         // [B][Tp][E]
+    const bf16_t* enc16;      // the same as bf16 (EB kernels), or null
     const float* psi; const int32_t* lens;
     const float* att;         // [B][Tp] this step's attention
     const float* dctx; long ld_dctx;   // [B][E] d loss / d context of this step
@@ -73,7 +74,11 @@ struct AttBwdArgs {
 // att_loc_post / att_conv_wgrad after the loop, from the saved s / f / d e / d f.
 // 8 waves per workgroup: a chunk's <= 20 frames are <= 3 per wave, which keeps the two per-frame phases short.
 constexpr int ATT_NW = 8, ATT_NT = 64 * ATT_NW;
-template <bool LOC, int AI, int EV = 4>                  // EV: float4 pieces of an enc row per lane (4: E <= 1024, 8: E <= 2048)
+template <bool LOC, int AI, int EV = 4, bool EB = false>  // EV: float4 pieces of an enc row per lane (4: E <= 1024, 8: E <= 2048);
+                                                          // EB: the rows come from the bf16 copy of enc (EV / 2 sixteen-byte pieces of
+                                                          // 8 values: half the bytes and half the row registers -- with E = 2 048 the fp32
+                                                          // form is 168 registers, one workgroup per CU, and the 360 workgroups of
+                                                          // BASELINE configs[4] run as two rounds)
 __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[32];
@@ -109,15 +114,22 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
     }
     // ... and so are this wave's enc rows (<= EV float4 per lane and row: E <= 256 EV on this path; the 6 x 1024 pBLSTM of
     // BASELINE configs[4] has E = 2048, and without this path its step was 48.7 us of dependent scalar loads)
-    const bool vec = (a.E & 3) == 0 && a.E <= 256 * EV && ((((uintptr_t)a.enc) & 15) == 0);
-    float4 er[ATT_ROWS][EV];
+    const bool vec = EB ? ((a.E & 7) == 0 && a.E <= 256 * EV) : ((a.E & 3) == 0 && a.E <= 256 * EV && ((((uintptr_t)a.enc) & 15) == 0));
+    float4 er[EB ? 1 : ATT_ROWS][EB ? 1 : EV];
+    u32x4 eb[EB ? ATT_ROWS : 1][EB ? EV / 2 : 1];
     if (vec) {
 #pragma unroll
         for (int r = 0; r < ATT_ROWS; ++r) {
             const int t = min(t0 + wave + ATT_NW * r, t0 + tcv - 1);
-            const float4* __restrict__ p = (const float4*)(a.enc + ((long)b * a.Tp + t) * a.E);
+            if constexpr (EB) {
+                const u32x4* __restrict__ p = (const u32x4*)(a.enc16 + ((long)b * a.Tp + t) * a.E);
 #pragma unroll
-            for (int k = 0; k < EV; ++k) er[r][k] = p[min(lane + 64 * k, a.E / 4 - 1)];
+                for (int k = 0; k < EV / 2; ++k) eb[r][k] = p[min(lane + 64 * k, a.E / 8 - 1)];
+            } else {
+                const float4* __restrict__ p = (const float4*)(a.enc + ((long)b * a.Tp + t) * a.E);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) er[r][k] = p[min(lane + 64 * k, a.E / 4 - 1)];
+            }
         }
     }
     float att_r[ATT_ROWS];
@@ -217,12 +229,25 @@ __global__ __launch_bounds__(ATT_NT) void att_bwd_step(AttBwdArgs a) {
         if (tt < tcv) {
             float acc = 0.f;
             const float* __restrict__ p = a.enc + ((long)b * a.Tp + t) * a.E;
-            if (vec) {
+            if (vec && EB) {
+#pragma unroll
+                for (int k = 0; k < EV / 2; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < a.E / 8) {
+                        const u32x4 v = eb[r][k];
+                        const float4 w0 = ((const float4*)dctx_l)[2 * i], w1 = ((const float4*)dctx_l)[2 * i + 1];
+                        acc += __uint_as_float(v[0] << 16) * w0.x + __uint_as_float(v[0] & 0xffff0000u) * w0.y +
+                               __uint_as_float(v[1] << 16) * w0.z + __uint_as_float(v[1] & 0xffff0000u) * w0.w +
+                               __uint_as_float(v[2] << 16) * w1.x + __uint_as_float(v[2] & 0xffff0000u) * w1.y +
+                               __uint_as_float(v[3] << 16) * w1.z + __uint_as_float(v[3] & 0xffff0000u) * w1.w;
+                    }
+                }
+            } else if (vec) {
 #pragma unroll
                 for (int k = 0; k < EV; ++k) {
                     const int i = lane + 64 * k;
                     if (i < a.E / 4) {
-                        const float4 v = er[r][k], w = ((const float4*)dctx_l)[i];
+                        const float4 v = er[EB ? 0 : r][EB ? 0 : k], w = ((const float4*)dctx_l)[i];
                         acc += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
                     }
                 }
@@ -809,6 +834,7 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     const size_t lds_cw = sizeof(float) * ((size_t)Tp + 2 * LOC_K + CW_KPT + LOC_C * (size_t)Tp);
     if (lds_e > 160 * 1024 || (loc && lds_cw > 160 * 1024)) return LAS_E_UNSUPPORTED;
     const bool fuse_pw = NL == 1;
+    const bool use_e16 = w.enc_bf16 && prec == LAS_PREC_BF16 && (E & 7) == 0 && E <= 2048 && ((((uintptr_t)w.enc_bf16) & 15) == 0);
     const bool drop = d->dropout > 0.f;
     if (pk && chain) {
         int rc = las_dec_pk_bwd(d, p, enc, psi, enc_len, st_, g_htop, bw_, st);
@@ -856,6 +882,7 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
         AttBwdArgs a{};
         a.B = B; a.Tp = Tp; a.E = E; a.A = A; a.TC = TC; a.NCH = NCH;
         a.enc = enc; a.psi = psi; a.lens = enc_len;
+        a.enc16 = use_e16 ? (const bf16_t*)w.enc_bf16 : nullptr;
         a.att = s.att + (long)(t + 1) * B * Tp;
         a.dctx = w.dxin + (long)t * B * XI + C; a.ld_dctx = XI;
         a.ctx = s.xin + (long)t * B * XI + C; a.ld_ctx = XI;
@@ -874,12 +901,15 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
             }
         }
         if (!loc) {
-            if (E > 1024) hipLaunchKernelGGL((att_bwd_step<false, 1, 8>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
+            if (use_e16 && E > 1024) hipLaunchKernelGGL((att_bwd_step<false, 1, 8, true>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
+            else if (use_e16) hipLaunchKernelGGL((att_bwd_step<false, 1, 4, true>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
+            else if (E > 1024) hipLaunchKernelGGL((att_bwd_step<false, 1, 8>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
             else hipLaunchKernelGGL((att_bwd_step<false, 1, 4>), dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);
         } else {
 #define LAS_ATT_GO(AIV)                                                                                           \
     {                                                                                                             \
-        auto k = E > 1024 ? att_bwd_step<true, AIV, 8> : att_bwd_step<true, AIV, 4>;                              \
+        auto k = use_e16 ? (E > 1024 ? att_bwd_step<true, AIV, 8, true> : att_bwd_step<true, AIV, 4, true>)       \
+                         : (E > 1024 ? att_bwd_step<true, AIV, 8> : att_bwd_step<true, AIV, 4>);                  \
         if (lds_e > 64 * 1024 && t == L - 1) LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e)); \
         hipLaunchKernelGGL(k, dim3(NCH, B), dim3(ATT_NT), lds_e, st, a);                                          \
     }

@@ -140,7 +140,7 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
 
 class DecBwdState(ctypes.Structure):
     _fields_ = [(n, P) for n in ('dgates', 'dxin', 'dq_pre', 'de', 'dh_carry', 'dc_carry', 'd_below', 'da', 'df',
-                                 'dpsi', 'acc', 'demb', 'pk_ws', 'pk_status')]
+                                 'dpsi', 'acc', 'demb', 'pk_ws', 'pk_status', 'enc_bf16')]
 
 
 def transpose2d(w):
@@ -187,6 +187,7 @@ class DecoderFn(torch.autograd.Function):
             seed, dropout, drop_seed = seed
         S = decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode, seed, dropout, drop_seed, status=status)
         ctx.S, ctx.W, ctx.cfg = S, W, (L, NL, loc, names)
+        ctx.enc16 = ops.twin(enc) if 'pk_ws' not in S else None      # (the per-step attention backward reads enc as bf16 in bf16 mode)
         DecoderFn.last_tok = S['tok']                     # int32 [L][B]: the token fed at every step (tests read the sampler's draws)
         ctx.save_for_backward(enc, psi, enc_len)
         h_top = S['hs'][NL - 1, 1:]
@@ -233,6 +234,8 @@ class DecoderFn(torch.autograd.Function):
         bw = DecBwdState()
         for k, v in Bw.items():
             setattr(bw, k, v.data_ptr())
+        if ctx.enc16 is not None and ctx.enc16.is_contiguous() and tuple(ctx.enc16.shape) == (B, Tp, E):
+            bw.enc_bf16 = ctx.enc16.data_ptr()
         st = S['_keep'][1]
         g_htop = g_htop.contiguous()
         tg = {n: ops.wgrad_target(W[n]) for n in names}

@@ -210,6 +210,8 @@ typedef struct {                    /* backward buffers (caller-owned); the driv
     void* pk_ws;                    /* las_decoder_pk_bwd_workspace_bytes(dims) bytes, or NULL: with it (and the conditions of the
                                        forward's pk_ws) the whole BPTT chain runs as ONE persistent launch (decoder_pk_bwd.hip) */
     int32_t* pk_status;             /* int32, caller-zeroed: LAS_E_TIMEOUT if a hand-off spin of that launch ran out */
+    const void* enc_bf16;           /* optional: enc as bf16 [B][Tp][E] (the twin its producer made for the psi GEMM).  bf16 mode, per-step
+                                       chain: d a = enc . d ctx reads it instead of the fp32 rows (half the bytes and row registers) */
 } las_dec_bwd_state;
 size_t las_decoder_pk_bwd_workspace_bytes(const las_dec_dims* dims);
 int64_t las_decoder_loc_acc_floats(int A);

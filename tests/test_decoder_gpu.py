@@ -323,6 +323,50 @@ def test_persistent_bptt_matches_per_step_path(mods, prec, B, Tp, E, A, C, V, L)
         assert np.abs(got - ref).max() <= lim, (k, float(np.abs(got - ref).max()), float(lim))
 
 
+@pytest.mark.parametrize('mode,E', [('loc', 2048), ('loc', 640), ('dot', 1280)])
+def test_per_step_backward_reads_enc_as_bf16(mods, mode, E):
+    """bf16 mode, per-step BPTT chain (two Speller layers): with enc's bf16 twin attached (as Seq2Seq.forward attaches it) att_bwd_step
+    takes d a = enc . d ctx from the bf16 rows (its EB variants; E = 2 048 is the 6 x 1024 pBLSTM's).  Against the same chain on the
+    fp32 rows: every gradient within 1e-2 of its largest entry (enc rounded to bf16 in ONE product of the chain)."""
+    ops, dec = mods
+    B, Tp, A, C, V, L, NL = 4, 50, 64, 32, 31, 5, 2
+    rng = np.random.RandomState(E + len(mode))
+    loc = mode == 'loc'
+    W = rand_weights(rng, V, C, E, A, NL, loc)
+    lens = sorted(rng.randint(Tp // 2, Tp + 1, size=B).tolist(), reverse=True); lens[0] = Tp
+    enc = np.zeros((B, Tp, E), np.float32)
+    for b, l in enumerate(lens):
+        enc[b, :l] = np.tanh(rng.randn(l, E))
+    psi = np.tanh(rng.randn(B, Tp, A)).astype(np.float32)
+    y = rng.randint(2, V, size=(B, L + 2)); y[:, 0] = 0
+    G = rng.randn(L, B, C).astype(np.float32)
+    names = dec.weight_names(NL, loc)
+    res = []
+    ops.set_precision('bf16')
+    for with_twin in (False, True):
+        Wg = {k: torch.tensor(W[k], device=DEV, requires_grad=True) for k in names}
+        enc_g = torch.tensor(enc, device=DEV, requires_grad=True)
+        if with_twin:
+            enc_g._bf16 = enc_g.detach().to(torch.bfloat16)
+        psi_g = torch.tensor(psi, device=DEV, requires_grad=True)
+        h_top, att = dec.DecoderFn.apply(enc_g, psi_g, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                         torch.tensor(y, device=DEV), L, NL, loc, None, 0, *[Wg[k] for k in names])
+        (h_top * torch.tensor(G, device=DEV)).sum().backward()
+        ops.join_side_stream()
+        torch.cuda.synchronize()
+        assert dec.DecoderFn.last_pk_bwd_ws is None
+        res.append(dict({'d enc': enc_g.grad.cpu().numpy(), 'd psi': psi_g.grad.cpu().numpy()},
+                        **{k: Wg[k].grad.cpu().numpy() for k in names if not k.startswith('char_trans')}))
+    differs = False
+    for k, ref in res[0].items():
+        if k == 'attention.gen_energy.bias':
+            continue
+        err = np.abs(res[1][k] - ref).max()
+        differs |= err > 0
+        assert err <= 1e-2 * np.abs(ref).max() + 1e-7, (k, float(err), float(np.abs(ref).max()))
+    assert differs, 'the bf16 rows were meant to be read (identical results: the fp32 path ran twice)'
+
+
 def test_odd_attention_dim_bf16_keeps_the_per_step_kernels(mods):
     """bf16 mode saves s = tanh(psi + q + u) as a 16-bit code that the persistent loops and the MFMA post-loop sums access as
     column PAIRS: an odd attention dim keeps the per-step kernels (2-byte accesses) and the VALU post-loop sums.  Their

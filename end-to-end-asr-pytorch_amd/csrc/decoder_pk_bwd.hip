@@ -534,15 +534,21 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.px + (size_t)(t & 1) * g.NCT * B * NGX * 16), 0,
                                                                          g.NCT * B * NGX * 16, 0x00020000);
             bool ok = true;
-            for (int i0 = 0; i0 < total && ok; i0 += PNT) {
-                const int i = i0 + threadIdx.x, pj = i / gpe, gc = i - pj * gpe, col = e0 + gc * V8, dst = pj * ES + gc * V8;
-                int off[1] = {(i < total && col < E) ? ((pj * B + b) * NGX + col / V8) * 16 : GR_OOB};
-                if (i < total && col >= E) {                                 // beyond E (last part): not d ctx columns, zeros
+            // two granules per lane and sweep (the 960 of the c3 shape are then ONE pass, one L2 round trip on the chain, instead of two)
+            for (int i0 = 0; i0 < total && ok; i0 += 2 * PNT) {
+                int off[2], dst[2];
 #pragma unroll
-                    for (int e = 0; e < V8; ++e) psum_l[dst + e] = 0.f;
+                for (int u = 0; u < 2; ++u) {
+                    const int i = i0 + u * PNT + threadIdx.x, pj = i / gpe, gc = i - pj * gpe, col = e0 + gc * V8;
+                    dst[u] = pj * ES + gc * V8;
+                    off[u] = (i < total && col < E) ? ((pj * B + b) * NGX + col / V8) * 16 : GR_OOB;
+                    if (i < total && col >= E) {                             // beyond E (last part): not d ctx columns, zeros
+#pragma unroll
+                        for (int e = 0; e < V8; ++e) psum_l[dst[u] + e] = 0.f;
+                    }
                 }
-                ok = pk_gr_sweep<1>(rp, off, (unsigned)n, abort_word, [&](int, const u32x4& gv) {
-                    float* o = psum_l + dst;
+                ok = pk_gr_sweep<2>(rp, off, (unsigned)n, abort_word, [&](int u, const u32x4& gv) {
+                    float* o = psum_l + dst[u];
                     if constexpr (PREC == LAS_PREC_BF16)
                         *(float4*)o = make_float4(__uint_as_float(gv[0] << 16), __uint_as_float(gv[0] & 0xffff0000u),
                                                   __uint_as_float(gv[1] << 16), __uint_as_float(gv[1] & 0xffff0000u));
@@ -558,7 +564,17 @@ __device__ __forceinline__ void pb_att_role(const PbArgs& a, char* smem) {
             float part4 = 0.f;
             if (threadIdx.x < 4 * ES) {
                 const int e = threadIdx.x >> 2, qd = threadIdx.x & 3;
-                for (int pj = qd; pj < g.NCT; pj += 4) part4 += psum_l[pj * ES + e];
+                // (five reads requested before the first add: as a rolled loop over the producers this was ten dependent LDS round
+                // trips on the chain; all ten at once do not fit the role's registers)
+                constexpr int PQ = 5;                                        // producers per round trip and thread
+#pragma unroll 1
+                for (int p0 = qd; p0 < g.NCT; p0 += 4 * PQ) {
+                    float pv4[PQ];
+#pragma unroll
+                    for (int k = 0; k < PQ; ++k) pv4[k] = psum_l[min(p0 + 4 * k, g.NCT - 1) * ES + e];
+#pragma unroll
+                    for (int k = 0; k < PQ; ++k) part4 += (p0 + 4 * k < g.NCT) ? pv4[k] : 0.f;
+                }
             }
             part4 += las_dpp<0x111, 0xf>(0.f, part4);
             part4 += las_dpp<0x112, 0xf>(0.f, part4);

@@ -187,6 +187,23 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
                     return;
                 }
             }
+            // ... and summed over the producers NOW, before the wait for d q_pre: the pieces of step t+1 are long there, while the
+            // d q_pre term is on the loop's chain (as one sum behind the d q_pre product this was 40 dependent LDS reads per thread
+            // between the attention role's publication and the cells' own)
+            __syncthreads();
+            float vp = 0.f;
+            if (ev) {
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                int pj = 0;
+                for (; pj + 3 < g.NCT; pj += 4) {
+                    v0 += ct2f(Pl[((size_t)pj * NB * 16 + er) * U + en]);
+                    v1 += ct2f(Pl[((size_t)(pj + 1) * NB * 16 + er) * U + en]);
+                    v2 += ct2f(Pl[((size_t)(pj + 2) * NB * 16 + er) * U + en]);
+                    v3 += ct2f(Pl[((size_t)(pj + 3) * NB * 16 + er) * U + en]);
+                }
+                for (; pj < g.NCT; ++pj) v0 += ct2f(Pl[((size_t)pj * NB * 16 + er) * U + en]);
+                vp = (v0 + v1) + (v2 + v3);
+            }
             PK_STAMP(1);
             // d q_pre of step t+1 arrives as tagged granules (pk_common.h): no counter, no poll-then-pull -- the sweep IS the
             // pull, one L2 round trip once the last part has stored (this hand-off is on the loop's chain; as flag + data it
@@ -229,8 +246,7 @@ __device__ __forceinline__ void pb_cell_role(const PbArgs& a, char* smem) {
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < PNW; ++w) v += Gl[(w * NB * 16 + er) * 17 + en];
-                for (int pj = 0; pj < g.NCT; ++pj) v += ct2f(Pl[((size_t)pj * NB * 16 + er) * U + en]);
-                dh += v;
+                dh += v + vp;
             }
             PK_STAMP(3);
         }

@@ -652,8 +652,13 @@ template <int K>
 __global__ __launch_bounds__(DPS_NT) void att_dpsi_kernel(LocPostArgs a) {
     __shared__ int lmax_s;
     const int b = blockIdx.y, t0 = blockIdx.x * DPS_FT, len = a.lens[b];
-    if (t0 >= len) return;
-    const int A = a.A, Tp = a.Tp, nf = min(DPS_FT, len - t0), nw = nf * A / 2, tid = threadIdx.x;
+    const int A = a.A, Tp = a.Tp, nf = max(0, min(DPS_FT, len - t0)), nw = nf * A / 2, tid = threadIdx.x;
+    {                                                    // rows beyond the utterance: zeros (the buffer is not pre-filled)
+        float* __restrict__ z = a.dpsi + ((long)b * Tp + t0 + nf) * A;
+        const int nz = (min(DPS_FT, Tp - t0) - nf) * A;
+        for (int i = tid; i < nz; i += DPS_NT) z[i] = 0.f;
+    }
+    if (nf == 0) return;
     const long step_e = (long)a.B * Tp, step_w = (long)a.B * Tp * A / 2;
     const float* __restrict__ dep = a.de + (long)b * Tp + t0;
     if (tid == 0) lmax_s = -1;
@@ -816,6 +821,8 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     if (loc) LAS_CHECK_ARG(w.df && w.de && w.dpsi && w.acc);
     // one persistent launch for the whole sequential chain when the shape / mode allows it and the caller gave the workspace
     const bool pk = w.pk_ws && w.pk_status && las_dec_pk_bwd_ws_bytes(d) > 0;
+    // behind the persistent loops in bf16 mode d psi is a stream of its own and the MFMA post-loop pass is left with parameter gradients (below)
+    const bool split_post = loc && pk && prec == LAS_PREC_BF16 && (A & 1) == 0 && A <= 512 && !las_fallback("LAS_LOC_POST_VALU");
     if (chain) {
         if (!pk) {       // (the persistent loop keeps the carries in registers and writes every element of d q_pre itself)
             LAS_HIP(hipMemsetAsync(w.dh_carry, 0, sizeof(float) * NL * BC, st));
@@ -823,8 +830,11 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
             LAS_HIP(hipMemsetAsync(w.dq_pre, 0, sizeof(float) * (size_t)L * B * A, st));
         }
         if (loc) {
-            LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
-            LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
+            // d f: the per-step chain reads the next step's rows over all T' frames (zeros beyond the utterance); the persistent loop
+            // exchanges its window through a buffer of its own and att_conv_wgrad stops at the utterance's length: no 57 MB fill at c3.
+            // d psi: att_dpsi_kernel writes every row (zeros beyond the utterance); the other post-loop kernels ADD to it.
+            if (!pk) LAS_HIP(hipMemsetAsync(w.df, 0, sizeof(float) * (size_t)L * B * LOC_C * Tp, st));
+            if (!split_post) LAS_HIP(hipMemsetAsync(w.dpsi, 0, sizeof(float) * (size_t)B * Tp * A, st));
             LAS_HIP(hipMemsetAsync(w.acc, 0, sizeof(float) * (size_t)B * acc_stride, st));
         }
     }
@@ -938,7 +948,6 @@ static int decoder_bwd_run(const las_dec_dims* d, const las_dec_params* p, const
     // the MFMA pass over s / f / d e is left with parameter gradients, which run with the other parameter sums; otherwise one pass
     // makes both.  (Summing d psi inside the persistent loop instead was measured at c3: as float atomics at the L2 the loop grew by
     // 5 us a step, as a read-modify-write pass at the end of every step by 9 us -- the attention role has no slack.)
-    const bool split_post = loc && pk && prec == LAS_PREC_BF16 && (A & 1) == 0 && A <= 512 && !las_fallback("LAS_LOC_POST_VALU");
     if (split_post && chain) {
         LocPostArgs q{};
         q.B = B; q.Tp = Tp; q.A = A; q.TC = TC; q.L = L; q.lens = enc_len;

@@ -118,13 +118,13 @@ def decoder_forward_raw(W, enc, psi, enc_len, y, L, NL, loc, step_mode=None, see
     A = psi.shape[-1]
     V, C = W['embed.weight'].shape
     dims = DecDims(B, Tp, E, A, C, NL, V, L, int(loc), ops._prec, float(dropout), int(drop_seed) & 0xffffffff)
+    S, st = alloc_state(dims, enc.device, status, persistent and step_mode is None and y is not None)
     packed = None
-    if ops._prec == 0 and USE_PACKED:
+    if ops._prec == 0 and USE_PACKED and 'pk_ws' not in S:      # (the persistent loop reads the plain weights: nothing to pack)
         packed = {'phi': pack_weights([W['attention.phi.weight']], A)}
         for l in range(NL):
             packed[f'cell{l}'] = pack_weights([W[f'decoder.layer{l}.weight_ih'], W[f'decoder.layer{l}.weight_hh']], 4 * C, cell_C=C)
     params = make_params(W, NL, loc, packed=packed)
-    S, st = alloc_state(dims, enc.device, status, persistent and step_mode is None and y is not None)
     S['_packed'] = packed
     sm = None
     if step_mode is not None:
@@ -205,12 +205,16 @@ class DecoderFn(torch.autograd.Function):
         dev = enc.device
         B, Tp, E, A, C, V = d.B, d.Tp, d.E, d.A, d.C, d.V
         f32 = dict(dtype=torch.float32, device=dev)
-        tr = {'phi': transpose2d(W['attention.phi.weight'])}
-        for l in range(NL):
-            tr[f'ih{l}'] = transpose2d(W[f'decoder.layer{l}.weight_ih'])
-            tr[f'hh{l}'] = transpose2d(W[f'decoder.layer{l}.weight_hh'])
+        # the persistent BPTT loop reads the plain weights: the transposed / packed copies are the per-step chain's
+        pk_bwd_bytes = L_.las_decoder_pk_bwd_workspace_bytes(ctypes.byref(d)) if ('pk_ws' in S and DecoderFn.persistent_bwd) else 0
+        tr = None
+        if not pk_bwd_bytes:
+            tr = {'phi': transpose2d(W['attention.phi.weight'])}
+            for l in range(NL):
+                tr[f'ih{l}'] = transpose2d(W[f'decoder.layer{l}.weight_ih'])
+                tr[f'hh{l}'] = transpose2d(W[f'decoder.layer{l}.weight_hh'])
         packed = None
-        if S.get('_packed') is not None:
+        if tr is not None and (S.get('_packed') is not None or (ops._prec == 0 and USE_PACKED)):
             packed = {}
             for l in range(NL):
                 packed[f'dx{l}'] = pack_weights([tr[f'ih{l}']], int(tr[f'ih{l}'].shape[0]))
@@ -225,8 +229,8 @@ class DecoderFn(torch.autograd.Function):
         if loc:
             Bw.update(df=torch.empty(L, B, LOC_C, Tp, **f32), dpsi=torch.empty(B, Tp, A, **f32),
                       acc=torch.empty(B, accf, **f32))
-        if 'pk_ws' in S and DecoderFn.persistent_bwd:    # the forward ran as one persistent launch: so does the BPTT chain
-            nb = L_.las_decoder_pk_bwd_workspace_bytes(ctypes.byref(d))
+        if pk_bwd_bytes:                                 # the forward ran as one persistent launch: so does the BPTT chain
+            nb = pk_bwd_bytes
             if nb:
                 Bw['pk_ws'] = torch.empty(nb, dtype=torch.uint8, device=dev)
                 Bw['pk_status'] = S['pk_status']

@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace -d $O -o $w --output-format csv -- python3 bench.py --workload $w --steps 8 --warmup 4 --no-cpu-baseline > $O/log 2>&1 || { tail $O/log; exit 5; }
 f=$(find $O -name "*kernel_trace.csv" | head -1)
-python3 tools/timeline.py $f --step $step --min-us 12 > $O/timeline.txt
+python3 tools/timeline.py $f --step $step --min-us ${3:-12} > $O/timeline.txt
 rm -f $f
 head -150 $O/timeline.txt

@@ -193,11 +193,14 @@ class DecoderFn(torch.autograd.Function):
         h_top = S['hs'][NL - 1, 1:]
         att = S['att'][1:]
         ctx.mark_non_differentiable(att)
+        ctx.set_materialize_grads(False)         # (no [L, B, T'] zero tensor for the attention maps' unused gradient)
         return h_top, att
 
     @staticmethod
     def backward(ctx, g_htop, _g_att):
         L_ = _lib.lib()
+        if g_htop is None:                       # (h_top unused by the loss: nothing flows back)
+            return (None,) * (9 + len(ctx.cfg[3]))
         enc, psi, enc_len = ctx.saved_tensors
         S, W = ctx.S, ctx.W
         L, NL, loc, names = ctx.cfg

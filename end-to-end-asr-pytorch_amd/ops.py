@@ -265,10 +265,14 @@ class CTCLossFn(torch.autograd.Function):
     def forward(ctx, logits, label, enc_len, tgt_len, blank):
         nll, la, ctx.saved = _ctc_fwd(logits.contiguous(), label, enc_len, tgt_len, blank)
         ctx.mark_non_differentiable(la)
+        ctx.set_materialize_grads(False)         # (no zero tensor of log_alpha's size for its unused gradient)
         return nll, la
 
     @staticmethod
     def backward(ctx, gnll, _gla):
+        if gnll is None:
+            ctx.saved = None
+            return None, None, None, None, None
         grad = _ctc_bwd(ctx.saved, gnll)
         ctx.saved = None
         return grad, None, None, None, None
@@ -722,6 +726,7 @@ class JointLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, att_pred, ctc_pred, y, ntok, enc_len, L, w):
         L_ = _lib.lib()
+        ctx.set_materialize_grads(False)         # (att_loss / ctc_loss are by-products: no zero fills for their gradients)
         dev = y.device
         f32 = dict(dtype=torch.float32, device=dev)
         att = ctc = datt = None
@@ -770,6 +775,8 @@ class JointLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _ga, _gc):
         L_ = _lib.lib()
+        if g is None:
+            return None, None, None, None, None, None, None
         g = g.contiguous().view(1).float()
         gatt = gctc = None
         if ctx.ctc is not None:

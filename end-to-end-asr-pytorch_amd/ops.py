@@ -554,6 +554,8 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
                                   I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), P(y16.data_ptr()) if y16 is not None else None,
                                   ptr(hx), ptr(gates), ptr(cs), ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
     with_twin(y, y16)
+    if sr == 1 and y16 is not None:
+        hf._bf16_2d = y16.view(T * B, ND * H)      # (y IS hf: the weight-gradient GEMMs of the backward pass read the same copy)
     return y, (x, lens, w_ih, w_hh, hf, gates, cs, status, sr, int(concat), _prec, x16, w_ih16 if twins_on() else None)
 
 
@@ -609,7 +611,9 @@ def _lstm_bwd(saved, gy, need_gx, targets=None):
         box = {}
 
         def part1():
-            box['hf16'] = twin(hf2, make=True)
+            box['hf16'] = getattr(hf, '_bf16_2d', None) if twins_on() else None
+            if box['hf16'] is None:
+                box['hf16'] = twin(hf2, make=True)
             box['e_hf'] = torch.cuda.Event()
             box['e_hf'].record(torch.cuda.current_stream())
             colsum(dgf, gb_ih, beta=1.0, out2=gb_hh)

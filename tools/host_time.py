@@ -10,7 +10,7 @@ config = dict(asr_model=cfg, clm=dict(enable=False), solver=dict(dataset='synthe
               train_set=['train'], batch_size=w['B'], apex=False, total_steps=10**9, tf_start=1.0, tf_end=1.0, dev_set=['dev'], dev_batch_size=w['B'],
               dev_step=10**9, test_set=['test'], decode_beam_size=1, synthetic=dict(T_max=w['T_max'], D=w['D'], V=w['V'], L_max=w['L_max'], time_reduction=tr, n_batches=1)))
 paras = argparse.Namespace(gpu=True, name='b', config='b.yaml', seed=0, ckpdir=tmp + '/c', logdir=tmp + '/l', load=None, verbose=False, njobs=1)
-ops.set_precision('bf16')
+ops.set_precision(w['prec'])
 t = solver.Trainer(config, paras); t.load_data(); t.set_model()
 x, y, lens = synth.make_batch(0, w['B'], w['T_max'], w['D'], w['V'], w['L_max'], tr, ctc=w['ctc'] > 0)
 x, y = x.cuda(), y.cuda(); hl = (lens, int((y != 0).sum(-1).max()))

@@ -56,7 +56,33 @@ def lib():
             fn.restype = Z if name.endswith('_bytes') else I
         L.las_error_string.restype = ctypes.c_char_p
         _lib = L
+        _granule_selftest(L)
     return _lib
+
+
+SELFTEST = None      # dict(torn=, finished=, timeouts=, ok=) of this process's start-up granule self-test (None: no GPU / skipped)
+
+
+def _granule_selftest(L, iters=2000):
+    """Once per process, on the current device: the 16-byte-granule property every persistent kernel's hand-off rests on
+    (csrc/selftest.hip).  If an observation is ever inconsistent -- or the test does not finish -- the flag-protocol
+    LSTM kernels and the per-step decoder kernels are selected for the rest of the process (the documented fallbacks)."""
+    global SELFTEST
+    import torch
+    if os.environ.get('LAS_SKIP_SELFTEST') or not torch.cuda.is_available():
+        return
+    ws = torch.empty(int(L.las_granule_selftest_bytes()), dtype=torch.uint8, device='cuda')
+    res = (ctypes.c_uint * 3)()
+    rc = L.las_granule_selftest(I(iters), P(ws.data_ptr()), res, P(torch.cuda.current_stream().cuda_stream))
+    expect = 2 * 64 * 64                      # lanes that must finish: 64 pairs x 2 sides x 64 lanes, both flavours summed -> x 2 below
+    SELFTEST = dict(rc=int(rc), torn=int(res[0]), finished=int(res[1]), timeouts=int(res[2]))
+    SELFTEST['ok'] = rc == 0 and res[0] == 0 and res[2] == 0 and res[1] == 2 * expect
+    if not SELFTEST['ok']:
+        import warnings
+        warnings.warn(f'liblas_hip: the tagged-granule self-test failed on this device ({SELFTEST}); using the flag-protocol LSTM '
+                      'kernels and the per-step decoder kernels (LAS_LSTM_NO_GR=1, LAS_DEC_NO_PK=1)')
+        os.environ['LAS_LSTM_NO_GR'] = '1'
+        os.environ['LAS_DEC_NO_PK'] = '1'
 
 
 def check(rc, what=''):

@@ -27,6 +27,14 @@ enum { LAS_ACT_NONE = 0, LAS_ACT_TANH = 1, LAS_ACT_RELU = 2 };
 int las_abi_version(void);
 const char* las_error_string(int code);
 
+/* Start-up self-test of the tagged-granule hand-offs (csrc/selftest.hip): workgroup pairs play `iters` rounds of ping-pong through
+ * 16-byte granules {hash(tag), tag} with the product kernels' store / poll instructions, inside one XCD (plain stores) and across
+ * XCDs (sc1 stores); every polled value must be consistent with its own tag.  result (HOST memory, 3 words): inconsistent
+ * observations, lanes that finished (16384 expected: 64 pairs x 2 sides x 64 lanes x 2 flavours), timeouts.  workspace: las_granule_selftest_bytes() device bytes.  Synchronises
+ * the stream.  A caller that sees result[0] != 0 or result[1] != 16384 must not use the granule kernels (LAS_LSTM_NO_GR, LAS_DEC_NO_PK). */
+size_t las_granule_selftest_bytes(void);
+int las_granule_selftest(int iters, void* workspace, unsigned* result, void* stream);
+
 /* ---- CTC loss with fused log-softmax ------------------------------------------------------
  * Replaces F.log_softmax(ctc_pred.transpose(0,1),-1) + torch.nn.CTCLoss(blank=0) at
  * src/solver.py:93,160 (and :253).  logits [B,T,V] raw, batch-major as src/asr.py:69 emits them.

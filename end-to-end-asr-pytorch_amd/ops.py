@@ -756,7 +756,18 @@ class JointLossFn(torch.autograd.Function):
                 nll, la, ctc_ctx = _ctc_fwd(ctc_pred.contiguous(), label, enc_len, ntok, 0)
                 c = torch.empty(1, **f32)
                 check(L_.las_norm_mean_fwd(ptr(nll), ptr(ntok), I(nll.shape[0]), ptr(c), cur_stream()), 'las_norm_mean_fwd')
-                return c, la, ctc_ctx
+                if ctx.needs_input_grad[1]:
+                    # The CTC gradient needs nothing of the attention branch: it is formed HERE, behind the loss's own forward
+                    # on the same (branch) stream, for an upstream gradient of 1 -- beside the attend-and-spell loops' FORWARD
+                    # instead of behind their end; backward() only scales it by the upstream gradient.  (With V = 5 000 and
+                    # 60 labels the BPTT loop is shorter than the beta scan + gradient row pass, and the encoder's backward
+                    # waited for the branch; at c3 the row pass no longer shares the chip with the BPTT loop: 15.65 -> 15.54 ms.)
+                    B = ntok.shape[0]
+                    gs = torch.empty(B, **f32)
+                    one = torch.ones(1, **f32)
+                    check(L_.las_norm_mean_bwd(ptr(one), F(w), ptr(ntok), I(B), ptr(gs), cur_stream()), 'las_norm_mean_bwd')
+                    return c, la, _ctc_bwd(ctc_ctx, gs)
+                return c, la, None
             if cs is None:
                 ctc, ctx.log_alpha, ctx.ctc = ctc_part()
             else:
@@ -784,11 +795,10 @@ class JointLossFn(torch.autograd.Function):
         g = g.contiguous().view(1).float()
         gatt = gctc = None
         if ctx.ctc is not None:
-            def ctc_part():
-                B = ctx.ntok.shape[0]
-                gs = torch.empty(B, dtype=torch.float32, device=g.device)
-                check(L_.las_norm_mean_bwd(ptr(g), F(ctx.w), ptr(ctx.ntok), I(B), ptr(gs), cur_stream()), 'las_norm_mean_bwd')
-                return _ctc_bwd(ctx.ctc, gs)
+            def ctc_part():                 # ctx.ctc: the gradient for an upstream gradient of 1 (formed in forward)
+                gctc = ctx.ctc
+                check(L_.las_scale_dev(ptr(gctc), LL(gctc.numel()), ptr(g), cur_stream()), 'las_scale_dev')
+                return gctc
             if ctx.branch is None:
                 gctc = ctc_part()
             else:                       # beside the decoder's BPTT: its consumer (the head's backward) runs on the same stream

@@ -114,7 +114,7 @@ def attach_pmc_traffic(roof, workload):
     stale = meta.get('kernel_sources_sha') != kernel_sources_sha()     # counters were taken on other kernel sources
     # multi-kernel brackets whose HBM traffic is that of ONE launch each of the named kernels (the persistent loops and the
     # post-loop sums of the same C-ABI call; the zero fills and the per-step fallback kernels are not counted)
-    group_kernels = {'decoder_bwd (L steps BPTT)': ('dec_pk_bwd_kernel', 'att_loc_post_mma', 'att_loc_post'),
+    group_kernels = {'decoder_bwd (L steps BPTT)': ('dec_pk_bwd_kernel', 'att_dpsi_kernel', 'att_loc_post_mma', 'att_loc_post'),
                      'decoder_fwd (L attend+spell steps)': ('dec_pk_fwd_kernel',)}
     for row in [roof] + roof.get('breakdown', []):
         if not row.get('single_kernel'):

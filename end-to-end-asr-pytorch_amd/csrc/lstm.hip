@@ -628,25 +628,29 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                 __builtin_amdgcn_raw_buffer_store_b64(h16, ry16, off16 == OOB ? OOB : off16 >> 1, 0, 0);
             }
         };
-        u32x4 x0[NQ], x1[NQ], x2[NQ];                    // three sets: a value is used three phases after its request
-        xload(0, x0); xload(1, x1); xload(2, x2);
-        xstore(0, x0); xload(3, x0);
+        // D register sets: a value is used D phases after its request.  Three sufficed while the x-projection came out of the
+        // L2 / MALL; at T = 1 200 (295 MB of it at the C2 shape) the rows come from HBM and a 3.2 us lead left the step waiting:
+        // 1.04 us per step at T = 600, 1.17 at 1 200, 1.28 at 2 400 (tools/sweep_lstm.py).  Six sets for one batch tile: 1.11 at
+        // T = 1 200, c3 15.53 -> 15.37 ms (four sets: 15.42; nine: slower -- the loads queue in front of the saved-activation stores).
+        constexpr int D = NB == 1 ? 6 : 3;
+        u32x4 xs[D][NQ];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xload(k, xs[k]);
+        xstore(0, xs[0]); xload(D, xs[0]);
         __syncthreads();                                 // barrier(0)
-        // phase s (between barrier(s) and barrier(s+1)): hand over step s+1's x-projection, request step s+4's, store step
-        // s-1.  (The only back edge follows the third phase, so the compiler's wait counts at the loop head stay exact.)
-        for (int s = 0;; s += 3) {
-            xstore(s + 1, x1); xload(s + 4, x1);
-            sflush(max(s - 1, 0), s > 0);
-            __syncthreads();
-            if (s + 1 >= a.T) break;
-            xstore(s + 2, x2); xload(s + 5, x2);
-            sflush(s, true);
-            __syncthreads();
-            if (s + 2 >= a.T) break;
-            xstore(s + 3, x0); xload(s + 6, x0);
-            sflush(s + 1, true);
-            __syncthreads();
-            if (s + 3 >= a.T) break;
+        // phase p (between barrier(p) and barrier(p+1)): hand over step p+1's x-projection, request step p+1+D's, store step
+        // p-1.  (The only back edge follows the D-th phase, so the compiler's wait counts at the loop head stay exact.)
+        for (int s = 0;; s += D) {
+            bool done = false;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                if (done) break;
+                xstore(s + k + 1, xs[(k + 1) % D]); xload(s + k + 1 + D, xs[(k + 1) % D]);
+                sflush(max(s + k - 1, 0), s + k > 0);
+                __syncthreads();
+                done = s + k + 1 >= a.T;
+            }
+            if (done) break;
         }
         sflush(a.T - 1, true);
         return;

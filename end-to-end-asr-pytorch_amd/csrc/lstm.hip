@@ -194,6 +194,9 @@ struct LstmArgs {
                               // backward kernel's dgf measured neutral)
     int pf;                   // forward: a fifth wave prefetches the x-projection rows into the L2 two steps ahead
     int pdelay;               // (diagnostic build) granule kernels: units of 64 cycles to sleep before a step's first poll
+    int fxI;                  // forward, granule kernel: > 0 = the layer's input projection is FUSED: `xproj` is the layer input x
+                              // [T][B][fxI] (fxI <= 96) and the kernel forms x W_ih^T itself (three extra MFMAs per step); 0: xproj
+    const float* w_ih;        // [ND*4H][fxI] (fused input projection only)
     void* tw;                 // bf16 twin of the launch's main output (forward: y; backward: d gates), written by the granule /
                               // 32-unit kernels next to the fp32 stores (the GEMMs behind the layer read it); null: none
 };
@@ -529,7 +532,12 @@ __device__ __forceinline__ u32x4 gr_poll(__amdgpu_buffer_rsrc_t rs, int off) {
 constexpr int GR_XLD = 16 * 4 + 4;        // floats per batch row of the x-projection / gate tiles in LDS: [16 units][4 gates] + pad
 constexpr int GR_HLD = 16 * 2 + 2;        // ... of the {h, c} tile
 
-template <int NB, int KS, int SWM = 4>     // SWM: 16-byte granules a lane sweeps per step (4: per-lane lists in registers; more: lists in LDS)
+// FX (one batch tile, narrow layer input: the bottom layer's 80 fbank dims): the input projection is fused.  The I/O wave hands
+// over x_t as a bf16 tile instead of the x-projection's rows, the compute waves hold their 16 rows of W_ih as three k-steps of
+// fragments and start the step's accumulators with x_t W_ih^T.  The projection GEMM of the bottom layer is pure output traffic
+// (K = 80: 295 MB written at the C2 shape, 118 us) that this kernel then read back from HBM, 245 KB per step.
+constexpr int FX_KS = 3, FX_LD = FX_KS * 32 + 8;        // k-steps of the fused projection (I <= 96), bf16 row stride of the x tile
+template <int NB, int KS, int SWM = 4, bool FX = false>     // SWM: 16-byte granules a lane sweeps per step (4: per-lane lists in registers; more: lists in LDS)
 __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                       const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -568,10 +576,10 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
         // ---- I/O wave.  Item = 4 consecutive units of one (batch row, gate): lane + 64 q -> row = item / 16,
         // gate = (item / 4) % 4, quarter = item % 4; 16-byte buffer accesses (H % 4 == 0), masked lanes use an
         // out-of-range offset instead of a branch, so the wave's code is straight-line and its waits are exact counts.
-        constexpr int NQ = NB * 4;
+        constexpr int NQ = FX ? 6 : NB * 4;              // FX: item = 4 consecutive input dims of one batch row: 16 x 24 items
         constexpr int OOB = 0x7ffffff0;
         const long nrow = (long)a.T * B;
-        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, (int)(nrow * ND4H * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, (int)(nrow * (FX ? a.fxI : ND4H) * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gates, 0, (int)(nrow * ND4H * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hf, 0, (int)(nrow * ND * H * 4), 0x00020000);
         __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * ND * H * 4), 0x00020000);
@@ -582,12 +590,28 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
             const int t = tstep(s);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
-                const int off = (row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * 4 * H + gi * H + j0 + u0) * 4) : OOB;
-                xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+                if constexpr (FX) {
+                    const int it = lane + 64 * q, row = it / 24, k0 = (it - row * 24) * 4;
+                    const int off = (row < Bl && k0 < a.fxI) ? (int)((((long)t * B + b0 + row) * a.fxI + k0) * 4) : OOB;      // (beyond the input width: zeros)
+                    xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+                } else {
+                    const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
+                    const int off = (row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * 4 * H + gi * H + j0 + u0) * 4) : OOB;
+                    xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+                }
             }
         };
         auto xstore = [&](int s, const u32x4 (&xr)[NQ]) {
+            if constexpr (FX) {                          // x_t as a bf16 tile [16][FX_LD] (in Xl's space), zeros beyond the rows / the width
+                bf16_t* xb = (bf16_t*)Xl + (s & 1) * 16 * FX_LD;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int it = lane + 64 * q, row = it / 24, k0 = (it - row * 24) * 4;
+                    if (row < 16)
+                        *(u32x2*)(xb + row * FX_LD + k0) = (u32x2){pack_bf16x2(__uint_as_float(xr[q][0]), __uint_as_float(xr[q][1])),
+                                                                 pack_bf16x2(__uint_as_float(xr[q][2]), __uint_as_float(xr[q][3]))};
+                }
+            } else {
             unsigned* xl = (unsigned*)Xl + (s & 1) * NB * 16 * GR_XLD;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -595,13 +619,14 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
                 unsigned* p = xl + row * GR_XLD + u0 * 4 + gi;
                 p[0] = xr[q][0]; p[4] = xr[q][1]; p[8] = xr[q][2]; p[12] = xr[q][3];
             }
+            }
         };
         auto sflush = [&](int s, bool valid) {           // saved activations of step s: LDS -> global (non-temporal)
             const int t = tstep(s);
             const unsigned* sg = (const unsigned*)Sg + (s & 1) * NB * 16 * GR_XLD;
             const unsigned* sh = (const unsigned*)Sh + (s & 1) * NB * 16 * GR_HLD;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int q = 0; q < NB * 4; ++q) {
                 const int it = lane + 64 * q, row = it >> 4, gi = (it >> 2) & 3, u0 = (it & 3) * 4;
                 const unsigned* p = sg + row * GR_XLD + u0 * 4 + gi;
                 const u32x4 v = {p[0], p[4], p[8], p[12]};
@@ -672,6 +697,22 @@ __global__ __launch_bounds__(NT + 64) void lstm_fwd_gr_kernel(LstmArgs a, const 
             for (int e = 0; e < 8; ++e) v[e] = (rowok && c + e < H) ? v[e] : 0.f;
             const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
             wfrag[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
+    // FX: the same 16 rows of W_ih, k = 32 ks + 8 fq + {0..7} of the input width (zeros beyond it)
+    bf16x8 xfrag[FX ? FX_KS : 1];
+    if constexpr (FX) {
+        const int jw = j0 + 4 * wave + (fr >> 2), gi = fr & 3, I_ = a.fxI;
+        const bool rowok = jw < H;
+        const float* wrow = a.w_ih + ((long)d * 4 * H + gi * H + min(jw, H - 1)) * I_;
+#pragma unroll
+        for (int ks = 0; ks < FX_KS; ++ks) {
+            const int c = ks * 32 + fq * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (rowok && c + e < I_) ? wrow[min(c + e, I_ - 1)] : 0.f;
+            const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            xfrag[ks] = __builtin_bit_cast(bf16x8, pk);
         }
     }
     // my cell elements: unit je (ul within the workgroup), batch rows bt * 16 + fr
@@ -789,7 +830,15 @@ GR_ST(1);
         const float* xl = Xl + (s & 1) * NB * 16 * GR_XLD;
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
-            acc[bt] = *(const f32x4*)(xl + (bt * 16 + fr) * GR_XLD + ul * 4) + bias;
+            if constexpr (FX) {                          // x_t W_ih^T: three MFMAs on the bf16 x tile the I/O wave handed over
+                const bf16_t* xb = (const bf16_t*)Xl + (s & 1) * 16 * FX_LD;
+                acc[bt] = bias;
+#pragma unroll
+                for (int ks = 0; ks < FX_KS; ++ks)
+                    acc[bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag[ks], *(const bf16x8*)(xb + fr * FX_LD + ks * 32 + fq * 8), acc[bt], 0, 0, 0);
+            } else {
+                acc[bt] = *(const f32x4*)(xl + (bt * 16 + fr) * GR_XLD + ul * 4) + bias;
+            }
             acc2[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (s > 0) {
@@ -1705,7 +1754,7 @@ void fill_args(LstmArgs& a, int T, int B, int H, int ND, int U, int sr, int conc
     if (sr == 1) { a.T_out = T; a.F_out = ND * H; }
     else if (concat) { a.T_out = T / sr; a.F_out = sr * ND * H; }
     else { a.T_out = (T + sr - 1) / sr; a.F_out = ND * H; }
-    a.y_is_hf = 0; a.wdirect = 0;
+    a.y_is_hf = 0; a.wdirect = 0; a.fxI = 0; a.w_ih = nullptr;
     // XCD-grouped launch when every XCD (32 CUs, one workgroup per CU) can hold the groups dealt to it
     const bool no_xl = las_fallback("LAS_LSTM_NO_XL") != nullptr;
     const int groups = ND * a.NS, gpl = (groups + 7) / 8;
@@ -1758,11 +1807,11 @@ size_t fwd_gr_lds(int H, int NB, int swm = 4) {
 size_t fwd_gr_ring_bytes(const LstmArgs& a) {
     return (size_t)16 * a.ND * HX_SLOTS * a.NS * a.H * ((a.Bs >> 4) * 3 + ((a.Bs & 15) + 5) / 6);
 }
-template <int NB, int KS, int SWM = 4>
+template <int NB, int KS, int SWM = 4, bool FX = false>
 int launch_fwd_gr(const LstmArgs& a, size_t lds, hipStream_t st, const float* xproj, const float* b_ih, const float* b_hh,
                   const float* w_hh, const int32_t* lens, float* y, float* hf, void* hx, float* gates, float* cs,
                   SyncWords* sync, int* status) {
-    auto k = lstm_fwd_gr_kernel<NB, KS, SWM>;
+    auto k = lstm_fwd_gr_kernel<NB, KS, SWM, FX>;
     LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if ((char*)hx != (char*)sync + sizeof(SyncWords))                    // (else: zeroed together with the sync words by the caller below)
         LAS_HIP(hipMemsetAsync(hx, 0, fwd_gr_ring_bytes(a), st));      // tags of earlier launches must not match
@@ -1899,7 +1948,8 @@ extern "C" int las_lstm_fwd_variant(int prec, int T, int B, int H, int ND) {
 
 static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                         const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
-                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
+                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream,
+                        int fxI = 0, const float* w_ih = nullptr);
 
 // y_bf16 (may be null): the bf16 twin of y, [T_out][B][F_out] -- the operand of the projection GEMM behind the layer.  The granule
 // and 32-unit kernels write it next to the fp32 stores (no second pass over y); behind the other kernels it is one cast pass.
@@ -1919,7 +1969,8 @@ extern "C" int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih,
 
 static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                         const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
-                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
+                        float* hf, void* tw, bool* tw_done, void* hx, float* gates, float* cs, void* sync, int* status, void* stream,
+                        int fxI, const float* w_ih) {
     LAS_CHECK_ARG(xproj && b_ih && b_hh && w_hh && lens && y && hf && hx && gates && cs && sync && status);
     int rc = check_common(T, B, H, ND, sr);
     if (rc) return rc;
@@ -1927,6 +1978,7 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
     int U = 16;
     LstmArgs a;
     if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
+        if (fxI > 0) return LAS_E_UNSUPPORTED;
         a.y_is_hf = (y == hf);
         a.tw = tw; *tw_done = true;
         if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
@@ -1979,11 +2031,19 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
     const bool gr_fwd = fwd_uses_gr(prec, T, B, H, ND, a, U, NB, KS);
     LAS_HIP(hipMemsetAsync(sync, 0, sizeof(SyncWords) + ((gr_fwd && (char*)hx == (char*)sync + sizeof(SyncWords)) ? fwd_gr_ring_bytes(a) : 0), st));
 #define LAS_FWD_ARGS a, lds, st, xproj, b_ih, b_hh, w_hh, lens, y, hf, hx, gates, cs, (SyncWords*)sync, status
+    if (fxI > 0 && !(gr_fwd && NB == 1 && KS >= 8 && KS <= 16 && fxI <= 32 * FX_KS && (fxI & 3) == 0 && (long)T * B * fxI * 4 < (1l << 31)))
+        return LAS_E_UNSUPPORTED;                        // (las_lstm_fwd_fx_ok: the caller runs the projection GEMM instead)
     if (gr_fwd) {
         *tw_done = true;
         // tagged-granule hand-off (lstm_fwd_gr_kernel): no flag, no drain, one barrier per step
         lds = fwd_gr_lds(H, NB);
         if (lds < MIN_LDS) lds = MIN_LDS;
+        if (fxI > 0) {                                   // fused input projection: `xproj` is the layer input
+            a.fxI = fxI; a.w_ih = w_ih;
+            if (KS == 8) return launch_fwd_gr<1, 8, 4, true>(LAS_FWD_ARGS);
+            if (KS == 10) return launch_fwd_gr<1, 10, 4, true>(LAS_FWD_ARGS);
+            return launch_fwd_gr<1, 16, 4, true>(LAS_FWD_ARGS);
+        }
         if (KS == 8)  { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 8>(LAS_FWD_ARGS))); }
         if (KS == 10) { LAS_NB_SWITCH(NB, return (launch_fwd_gr<NB_ <= 2 ? NB_ : 1, 10>(LAS_FWD_ARGS))); }
         if (KS == 16) { return launch_fwd_gr<1, 16>(LAS_FWD_ARGS); }
@@ -2000,6 +2060,32 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
     }
 #undef LAS_FWD_ARGS
     return LAS_E_BADARG;
+}
+
+// The same with the layer's input projection FUSED (bf16 mode, granule kernel with one batch tile per slice, input width I <= 96
+// and a multiple of 4: las_lstm_fwd_fx_ok): x [T][B][I] and w_ih [ND*4H][I] instead of xproj = x W_ih^T -- the bottom layer's
+// projection GEMM (K = 80: pure output traffic) and the kernel's read-back of its 4H-wide rows disappear.
+extern "C" int las_lstm_fwd_fx_ok(int prec, int T, int B, int H, int ND, int I) {
+    if (prec != LAS_PREC_BF16 || I < 4 || I > 32 * FX_KS || (I & 3) || (long)T * B * I * 4 >= (1l << 31)) return 0;
+    if (las_lstm_fwd_variant(prec, T, B, H, ND) != 1) return 0;
+    LstmArgs a;
+    fill_args(a, T, B, H, ND, 16, 1, 0);
+    const int ksteps = (H + 31) / 32;
+    return las_pick_nb(a.Bs) == 1 && ksteps <= 16 && !(ND * ((H + 7) / 8) <= las_cu_count() && !a.xl && H == 512);
+}
+extern "C" int las_lstm_rec_fwd_fx(int prec, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                                   const float* w_hh, const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y,
+                                   float* hf, void* y_bf16, void* hx, float* gates, float* cs, void* sync, int* status, void* stream) {
+    LAS_CHECK_ARG(x && w_ih && I > 0);
+    bool in_kernel = false;
+    int rc = rec_fwd_impl(prec, x, b_ih, b_hh, w_hh, lens, T, B, H, ND, sr, concat, y, hf, y_bf16, &in_kernel, hx, gates, cs, sync,
+                          status, stream, I, w_ih);
+    if (rc == LAS_OK && y_bf16 && !in_kernel) {
+        int T_out, F_out;
+        las_lstm_out_shape(T, H, ND, sr, concat, &T_out, &F_out);
+        rc = las_cast_bf16(y, y_bf16, (int64_t)T_out * B * F_out, stream);
+    }
+    return rc;
 }
 
 static int rec_bwd_impl(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,

@@ -533,8 +533,15 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     T, B, Iin = x.shape
     ND, H4, H = w_hh.shape
     dev = x.device
-    x16 = x16.reshape(T * B, Iin) if x16 is not None and x16.is_contiguous() else twin(x.view(T * B, Iin), make=True)
-    xproj = gemm(x.view(T * B, Iin), w_ih, transB=True, A16=x16, B16=w_ih16 if twins_on() else None)
+    # a narrow layer input (the bottom layer's 80 fbank dims): the recurrence kernel forms x W_ih^T itself (las_lstm_rec_fwd_fx) --
+    # no projection GEMM (K = 80: 295 MB of output at the C2 shape) and no read-back of its rows
+    fx = bool(L_.las_lstm_fwd_fx_ok(I(_prec), I(T), I(B), I(H), I(ND), I(Iin)))
+    xproj = None
+    if not fx:
+        x16 = x16.reshape(T * B, Iin) if x16 is not None and x16.is_contiguous() else twin(x.view(T * B, Iin), make=True)
+        xproj = gemm(x.view(T * B, Iin), w_ih, transB=True, A16=x16, B16=w_ih16 if twins_on() else None)
+    else:
+        x16 = x16.reshape(T * B, Iin) if x16 is not None and x16.is_contiguous() else None
     T_out, F_out = lstm_out_shape(T, H, ND, sr, concat)
     hf = torch.empty(T, B, ND * H, dtype=torch.float32, device=dev)
     y = hf if sr == 1 else torch.empty(T_out, B, F_out, dtype=torch.float32, device=dev)
@@ -550,9 +557,14 @@ def _lstm_fwd(x, lens, w_ih, w_hh, b_ih, b_hh, sr, concat, status, w_ih16=None):
     y16 = torch.empty(y.shape, dtype=torch.bfloat16, device=dev) if twins_on() and y.numel() >= TWIN_MIN_ELEMS else None
     kname = ('lstm_fwd_kernel', 'lstm_fwd_gr_kernel', 'lstm_fwd_x32_kernel')[L_.las_lstm_fwd_variant(I(_prec), I(T), I(B), I(H), I(ND))]
     with _Timed(kname, 2.0 * ND * T * B * H4 * H, 'flop', single=True, dep_steps=T):
-        check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
-                                  I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), P(y16.data_ptr()) if y16 is not None else None,
-                                  ptr(hx), ptr(gates), ptr(cs), ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
+        if fx:
+            check(L_.las_lstm_rec_fwd_fx(I(_prec), ptr(x), I(Iin), ptr(w_ih.contiguous()), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B),
+                                         I(H), I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), P(y16.data_ptr()) if y16 is not None else None,
+                                         ptr(hx), ptr(gates), ptr(cs), ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd_fx')
+        else:
+            check(L_.las_lstm_rec_fwd(I(_prec), ptr(xproj), ptr(b_ih), ptr(b_hh), ptr(w_hh), ptr(lens), I(T), I(B), I(H),
+                                      I(ND), I(sr), I(int(concat)), ptr(y), ptr(hf), P(y16.data_ptr()) if y16 is not None else None,
+                                      ptr(hx), ptr(gates), ptr(cs), ptr(sync), ptr(status), cur_stream()), 'las_lstm_rec_fwd')
     with_twin(y, y16)
     if sr == 1 and y16 is not None:
         hf._bf16_2d = y16.view(T * B, ND * H)      # (y IS hf: the weight-gradient GEMMs of the backward pass read the same copy)

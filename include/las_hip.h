@@ -103,6 +103,13 @@ int las_lstm_resident_wgs(int prec, int T, int B, int H, int ND);      /* workgr
 int las_lstm_rec_fwd(int prec, const float* xproj, const float* b_ih, const float* b_hh, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
                      void* y_bf16, void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
+/* rec_fwd with the layer's input projection fused (x [T][B][I], w_ih [ND*4H][I] instead of xproj): bf16 mode, granule kernel, one
+ * batch tile per slice, I <= 96 and a multiple of 4 -- las_lstm_fwd_fx_ok says whether a shape qualifies (else LAS_E_UNSUPPORTED and
+ * the caller runs las_gemm + las_lstm_rec_fwd).  The bottom layer's projection is K = I = 80: 295 MB of output at the C2 shape. */
+int las_lstm_fwd_fx_ok(int prec, int T, int B, int H, int ND, int I);
+int las_lstm_rec_fwd_fx(int prec, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                        const float* w_hh, const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, float* y, float* hf,
+                        void* y_bf16, void* hx, float* gates, float* cs, void* sync, int* status, void* stream);
 int las_lstm_rec_bwd(int prec, const float* dy, const float* gates, const float* cs, const float* w_hh,
                      const int32_t* lens, int T, int B, int H, int ND, int sr, int concat, void* dgx, float* dgf,
                      void* dgf_bf16, void* sync, int* status, void* stream);

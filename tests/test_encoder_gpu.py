@@ -188,7 +188,10 @@ def test_lstm_shapes_vs_oracle(ops, T, B, Iin, H, prec):
     close(b_ih.grad / scale, g_bi / scale, tol)
 
 
-@pytest.mark.parametrize('T,B,Iin,H,sr', [(23, 24, 64, 1024, 2), (31, 24, 160, 320, 2), (19, 24, 32, 512, 1)])
+@pytest.mark.parametrize('T,B,Iin,H,sr', [(23, 24, 64, 1024, 2), (31, 24, 160, 320, 2), (19, 24, 32, 512, 1),
+                                          # the bottom layer's shape (80 fbank dims; 40 / 12: k-steps partly beyond the width): the
+                                          # recurrence kernel forms x W_ih^T itself (las_lstm_rec_fwd_fx; asserted below)
+                                          (37, 24, 80, 320, 2), (21, 12, 40, 320, 1), (17, 24, 12, 160, 1)])
 def test_lstm_bf16_forward_tight(ops, T, B, Iin, H, sr):
     """bf16 mode against the oracle run with the SAME operand rounding (bf16 RNE operands, fp32 sums and state): 2e-3
     instead of the 5e-2 that separates bf16 from the reference's pure-fp32 arithmetic -- a wrong low-order term would
@@ -215,6 +218,10 @@ def test_lstm_bf16_forward_tight(ops, T, B, Iin, H, sr):
     torch.cuda.synchronize()
     assert int(status.item()) == 0
     close(y, yr.numpy(), dict(atol=2e-3, rtol=2e-3))
+    if Iin <= 96 and H <= 512:
+        import importlib
+        _lib = importlib.import_module('end-to-end-asr-pytorch_amd._lib')
+        assert _lib.lib().las_lstm_fwd_fx_ok(0, T, B, H, 2, Iin) == 1, 'this shape was meant to take the fused input projection'
 
 
 @pytest.mark.parametrize('T,B,Iin,H,sr', [(19, 24, 64, 1024, 2), (31, 24, 160, 320, 2), (19, 24, 32, 512, 1)])

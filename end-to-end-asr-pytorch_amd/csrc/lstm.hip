@@ -1978,7 +1978,8 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
     int U = 16;
     LstmArgs a;
     if (use_x32(prec, T, B, H, ND, sr, concat, a)) {
-        if (fxI > 0) return LAS_E_UNSUPPORTED;
+        if (fxI > 0 && (fxI > 32 * FX_KS || (fxI & 3) || (long)T * B * fxI * 4 >= (1l << 31))) return LAS_E_UNSUPPORTED;
+        a.fxI = fxI; a.w_ih = w_ih;
         a.y_is_hf = (y == hf);
         a.tw = tw; *tw_done = true;
         if (a.y_is_hf && sr != 1) return LAS_E_BADARG;
@@ -1991,7 +1992,7 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
         if (lds < MIN_LDS) lds = MIN_LDS;
 #define LAS_X32_FWD(KS_)                                                                                                   \
     {                                                                                                                     \
-        auto k = lstm_fwd_x32_kernel<KS_>;                                                                                \
+        auto k = fxI > 0 ? lstm_fwd_x32_kernel<KS_, true> : lstm_fwd_x32_kernel<KS_, false>;                              \
         LAS_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         hipLaunchKernelGGL(k, dim3(lstm_grid(a)), dim3(X32_NT), lds, st, a, xproj, b_ih, b_hh, w_hh, lens, y, hf, (u32x4*)hx, \
                            gates, cs, (SyncWords*)sync, status);                                                          \
@@ -2067,7 +2068,9 @@ static int rec_fwd_impl(int prec, const float* xproj, const float* b_ih, const f
 // projection GEMM (K = 80: pure output traffic) and the kernel's read-back of its 4H-wide rows disappear.
 extern "C" int las_lstm_fwd_fx_ok(int prec, int T, int B, int H, int ND, int I) {
     if (prec != LAS_PREC_BF16 || I < 4 || I > 32 * FX_KS || (I & 3) || (long)T * B * I * 4 >= (1l << 31)) return 0;
-    if (las_lstm_fwd_variant(prec, T, B, H, ND) != 1) return 0;
+    const int var = las_lstm_fwd_variant(prec, T, B, H, ND);
+    if (var == 2) return 1;                              // the 32-unit kernel: one batch tile by construction
+    if (var != 1) return 0;
     LstmArgs a;
     fill_args(a, T, B, H, ND, 16, 1, 0);
     const int ksteps = (H + 31) / 32;

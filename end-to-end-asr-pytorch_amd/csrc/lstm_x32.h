@@ -34,7 +34,7 @@ constexpr int X32_NT = 512;                 // eight waves
 constexpr int X32_XLD = 32 * 4 + 4;         // floats per batch row of the [32 units][4 gates] tiles
 constexpr int X32_HLD = 32 * 2 + 2;         // ... of the {h, c} tile
 
-template <int KS>
+template <int KS, bool FX = false>                  // FX: the layer's input projection fused, as in lstm_fwd_gr_kernel (input width <= 96)
 __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const float* __restrict__ xproj,
                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                const float* __restrict__ w_hh, const int32_t* __restrict__ lens,
@@ -85,6 +85,21 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
             wfrag[ks] = __builtin_bit_cast(bf16x8, pk);
         }
     }
+    bf16x8 xfrag[FX ? FX_KS : 1];                      // FX: the same 16 rows of W_ih over the input width
+    if constexpr (FX) {
+        const int jw = j0 + 4 * wave + (fr >> 2), gi = fr & 3, I_ = a.fxI;
+        const bool rowok = jw < H;
+        const float* wrow = a.w_ih + ((long)d * 4 * H + gi * H + min(jw, H - 1)) * I_;
+#pragma unroll
+        for (int ks = 0; ks < FX_KS; ++ks) {
+            const int c = ks * 32 + fq * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (rowok && c + e < I_) ? wrow[min(c + e, I_ - 1)] : 0.f;
+            const u32x4 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            xfrag[ks] = __builtin_bit_cast(bf16x8, pk);
+        }
+    }
     const int ul = 4 * wave + fq, je = j0 + ul;
     const bool evu = je < H;
     float c_state = 0.f;
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
     // ---- global I/O of waves 4-7.  x-projection item = 4 consecutive units of one (batch row, gate): 16 x 4 x 8 = 512 items,
     // two per I/O lane; {h, c, y} item = 4 consecutive units of one batch row: 128 items (I/O lanes < 128)
     const long nrow = (long)a.T * B;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, (int)(nrow * ND4H * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xproj, 0, (int)(nrow * (FX ? a.fxI : ND4H) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gates, 0, (int)(nrow * ND4H * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)hf, 0, (int)(nrow * NDH * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cs, 0, (int)(nrow * NDH * 4), 0x00020000);
@@ -123,12 +138,29 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
         const int t = tstep(s);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            if constexpr (FX) {                          // item = 4 consecutive input dims of one batch row: 16 x 24 items
+                const int it = il + 256 * q, row = it / 24, k0 = (it - row * 24) * 4;
+                const int off = (io && it < 384 && row < Bl && k0 < a.fxI) ? (int)((((long)t * B + b0 + row) * a.fxI + k0) * 4) : OOB;
+                xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            } else {
             const int it = il + 256 * q, row = it >> 5, gi = (it >> 3) & 3, u0 = (it & 7) * 4;
             const int off = (io && row < Bl && j0 + u0 < H) ? (int)((((long)t * B + b0 + row) * ND4H + d * 4 * H + gi * H + j0 + u0) * 4) : OOB;
             xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            }
         }
     };
     auto xstore = [&](int s, const u32x4 (&xr)[2]) __attribute__((always_inline)) {
+        if constexpr (FX) {                              // x_t as a bf16 tile [16][FX_LD] (in Xl's space)
+            bf16_t* xb = (bf16_t*)Xl + (s & 1) * 16 * FX_LD;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int it = il + 256 * q, row = it / 24, k0 = (it - row * 24) * 4;
+                if (it < 384)
+                    *(u32x2*)(xb + row * FX_LD + k0) = (u32x2){pack_bf16x2(__uint_as_float(xr[q][0]), __uint_as_float(xr[q][1])),
+                                                             pack_bf16x2(__uint_as_float(xr[q][2]), __uint_as_float(xr[q][3]))};
+            }
+            return;
+        }
         unsigned* xl = (unsigned*)Xl + (s & 1) * 16 * X32_XLD;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -228,7 +260,16 @@ __global__ __launch_bounds__(X32_NT) void lstm_fwd_x32_kernel(LstmArgs a, const 
         const bf16_t* buf = Hl + (s & 1) * 16 * ld;
         // ---- gate pre-activations of my four units: x-projection + bias + W_hh h_{t-1}
         const float* xl = Xl + (s & 1) * 16 * X32_XLD;
-        f32x4 acc = *(const f32x4*)(xl + fr * X32_XLD + ul * 4) + bias;
+        f32x4 acc;
+        if constexpr (FX) {
+            const bf16_t* xb = (const bf16_t*)Xl + (s & 1) * 16 * FX_LD;
+            acc = bias;
+#pragma unroll
+            for (int ks = 0; ks < FX_KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag[ks], *(const bf16x8*)(xb + fr * FX_LD + ks * 32 + fq * 8), acc, 0, 0, 0);
+        } else {
+            acc = *(const f32x4*)(xl + fr * X32_XLD + ul * 4) + bias;
+        }
         f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0 && !(a.pdelay & 256)) {
             constexpr int CH = 8, NCH = KS / CH;
